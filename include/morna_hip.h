@@ -1,0 +1,152 @@
+/*
+ * morna_hip.h -- C ABI of libmorna_hip.so, the MI355X (gfx950) implementation of
+ * morna's index-build + nearest-neighbour search hot path.
+ *
+ * This is the drop-in boundary: the entry points are what a binding for the
+ * reference's two native dependencies on this path would call.  Each one cites
+ * the reference interface it replaces (file:line under commanderson/morna).
+ *
+ *   annoy.AnnoyIndex (C++ extension, used angular)  morna.py:26, 166, 543
+ *   mmh3.hash        (C extension)                  morna.py:20, 369, 591, 625
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every buffer is caller-owned HOST memory
+ *     unless the name says _dev; the library copies during the call and never
+ *     retains a host pointer.
+ *   - every function returns 0 on success or a negative MORNA_E_* code; the
+ *     message for the calling thread is available from morna_last_error().
+ *   - one host thread per handle; the handle owns its HIP stream.
+ *   - ids are dense internal ids 0..n_items-1 (morna.py:378-382).
+ *   - distances are annoy "angular": sqrt(max(2 - 2 cos, 0)).
+ */
+#ifndef MORNA_HIP_H
+#define MORNA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MORNA_OK            0
+#define MORNA_E_INVALID    -1   /* bad argument              -> ValueError  */
+#define MORNA_E_HIP        -2   /* HIP runtime failure       -> RuntimeError */
+#define MORNA_E_STATE      -3   /* call order (not built...) -> RuntimeError */
+#define MORNA_E_RANGE      -4   /* id out of range           -> IndexError  */
+#define MORNA_E_IO         -5   /* save / load               -> IOError     */
+#define MORNA_E_EMPTY      -6   /* no items (morna.py:399-403) -> ValueError */
+
+typedef struct morna_index morna_index;
+
+/* AnnoyIndex(dim, metric='angular')                          morna.py:166, 543, 1171 */
+int morna_index_create(int32_t dim, int32_t device, morna_index **out);
+int morna_index_destroy(morna_index *h);
+const char *morna_last_error(void);
+
+/* mmh3.hash(key) -- host mirror of the device hash            morna.py:369, 591, 625 */
+int32_t morna_hash32(const uint8_t *key, int64_t len);
+
+/* ---- items --------------------------------------------------------------- */
+
+/* AnnoyIndex.add_item(i, vector): fp64 -> fp32 happens here    morna.py:406, 423 */
+int morna_add_item(morna_index *h, int32_t id, const double *v);
+/* bulk form: rows[n][dim] fp32 become items first_id .. first_id+n-1 */
+int morna_add_items_f32(morna_index *h, int32_t first_id, const float *rows, int64_t n);
+
+/*
+ * Fused replacement for the add_junction loop + add_item hand-off
+ * (morna.py:344-388, 405-424): J kept junction lines in FILE ORDER.
+ *   key_bytes/key_off[J+1]  the "chrom start end" strings        morna.py:849
+ *   row_ptr[J+1]            extent of each line's lists
+ *   item_ids[nnz]           INTERNAL id of each sample           morna.py:377-382
+ *   cov[nnz]                coverages                            morna.py:852
+ *   idf[J]                  log(sample_count / cumulative freq)  morna.py:372-374
+ *                           (host libm, so that it is bit-identical to Python)
+ * stage = host -> HBM copy only; build_features = the kernels (hash, signed
+ * column, fp64 accumulation in file order, fp64 -> fp32, row norms).
+ */
+int morna_stage_junctions(morna_index *h, const uint8_t *key_bytes, const int64_t *key_off, int64_t J,
+                          const int64_t *row_ptr, const int32_t *item_ids, const int32_t *cov,
+                          const double *idf);
+int morna_build_features(morna_index *h, int64_t n_items);
+int morna_unstage_junctions(morna_index *h);
+/* device hash of staged or given keys, for tests: hash/col/sign per key */
+int morna_hash_keys(morna_index *h, const uint8_t *key_bytes, const int64_t *key_off, int64_t J,
+                    int32_t *hash_out, int32_t *col_out, int32_t *sign_out);
+
+/* AnnoyIndex.get_n_items()                                     morna.py:1174 */
+int64_t morna_get_n_items(const morna_index *h);
+/* AnnoyIndex.get_item_vector(i)                                morna.py:702 */
+int morna_get_item_vector(morna_index *h, int32_t id, float *out);
+/* whole matrix / squared norms, for tests */
+int morna_get_items(morna_index *h, float *rows_out /* [n][dim] */);
+int morna_get_norms2(morna_index *h, float *out /* [n] */);
+
+/* ---- forest -------------------------------------------------------------- */
+
+/* AnnoyIndex.build(n_trees); seed 0 selects annoy's default 123456789   morna.py:425 */
+int morna_build(morna_index *h, int32_t n_trees, uint32_t seed);
+int32_t morna_get_n_trees(const morna_index *h);
+
+typedef struct {
+    int64_t n_items, dim, leaf_capacity;   /* K = dim + 2 */
+    int64_t n_trees, n_nodes, n_split, n_leaves, max_depth;
+    int64_t split_attempts;                /* create_split calls (incl. rejected) */
+    int64_t split_rows;                    /* sum of |node| over those calls      */
+    int64_t fallback_nodes;                /* nodes randomised (imbalance > 0.99) */
+} morna_forest_stats;
+int morna_get_forest_stats(const morna_index *h, morna_forest_stats *out);
+/*
+ * Forest dump for structural tests.  node_rec[n_nodes][6] =
+ * {kind (0 split, 1 leaf), tree, start, count, child0, child1}; perm[n_trees][n_items];
+ * hyperplanes[n_split][dim] in the order given by hp_node[n_split] (node id).
+ * Any output pointer may be NULL.
+ */
+int morna_get_forest(morna_index *h, int32_t *node_rec, int32_t *perm, float *hyperplanes, int32_t *hp_node);
+
+/* ---- search -------------------------------------------------------------- */
+
+/*
+ * AnnoyIndex.get_nns_by_vector(v, n, search_k, include_distances)  morna.py:651, 659
+ * batched over nq queries; q[nq][dim] fp32.  search_k = -1 -> k * n_trees.
+ * ids_out[nq][k] (-1 padded), dist_out[nq][k] (may be NULL), count_out[nq] (may be NULL).
+ */
+int morna_get_nns_by_vector(morna_index *h, const float *q, int64_t nq, int32_t k, int32_t search_k,
+                            int32_t *ids_out, float *dist_out, int32_t *count_out);
+/* AnnoyIndex.get_nns_by_item(i, n, search_k, include_distances)    morna.py:762, 769, 1191 */
+int morna_get_nns_by_item(morna_index *h, const int32_t *items, int64_t nq, int32_t k, int32_t search_k,
+                          int32_t *ids_out, float *dist_out, int32_t *count_out);
+/*
+ * MornaSearch.exact_search_nn + cosine_distance                   morna.py:681-716, 101-114
+ * q[nq][dim] fp64 (the un-rounded query_sample); distances fp64, accumulated in
+ * the reference's sequential order; ties resolved as bisect_left does.
+ */
+int morna_exact_search(morna_index *h, const double *q, int64_t nq, int32_t k,
+                       int32_t *ids_out, double *dist_out, int32_t *count_out);
+
+/* ---- persistence (stands in for AnnoyIndex.save / load)      morna.py:439, 544 */
+int morna_save(morna_index *h, const char *path);
+int morna_load(morna_index *h, const char *path);
+
+/* ---- measurement --------------------------------------------------------- */
+
+enum {
+    MORNA_T_FEATURES = 0,   /* hash + accumulate + transpose/convert + norms   */
+    MORNA_T_TWO_MEANS = 1,  /* forest: centroid kernel                         */
+    MORNA_T_SPLIT = 2,      /* forest: hyperplane margin / side kernel (dominant) */
+    MORNA_T_PARTITION = 3,  /* forest: stable partition                        */
+    MORNA_T_QUERY = 4,      /* traversal + refine + top-k                      */
+    MORNA_T_EXACT = 5,      /* exact scan + re-rank                            */
+    MORNA_T_COUNT = 6
+};
+/* HIP-event timing of the kernels on the handle's own stream */
+int morna_timer_enable(morna_index *h, int32_t on);
+int morna_timer_reset(morna_index *h);
+/* ms = summed event time, launches, bytes = algorithmic bytes of those launches */
+int morna_timer_read(morna_index *h, int32_t which, double *ms, int64_t *launches, int64_t *bytes);
+int morna_synchronize(morna_index *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MORNA_HIP_H */

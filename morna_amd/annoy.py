@@ -1,0 +1,201 @@
+"""AnnoyIndex-shaped front end of the HIP library.
+
+Mirrors the surface of ``annoy.AnnoyIndex`` that morna uses (reference call
+sites in commanderson/morna morna.py): constructor 166/543/1171, ``add_item``
+406/423, ``build`` 425, ``save`` 439, ``load`` 544/1172, ``get_nns_by_vector``
+651/659, ``get_nns_by_item`` 762/769/1191, ``get_item_vector`` 702,
+``get_n_items`` 1174 -- same positional arguments, same return shapes
+(``include_distances=True`` -> ``(ids, distances)``, else a bare list).
+
+Everything numeric happens in libmorna_hip.so on the MI355X; this module only
+marshals numpy buffers through ctypes.  Batched variants (``*_batch``) expose
+what the C ABI really does: many queries per launch.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib, ptr
+
+
+class AnnoyIndex(object):
+    def __init__(self, f, metric='angular', device=0):
+        if metric != 'angular':
+            raise ValueError("morna uses AnnoyIndex(dim, metric='angular') only (morna.py:166); got %r" % (metric,))
+        self.f = int(f)
+        self._h = C.c_void_p()
+        check(lib().morna_index_create(self.f, int(device), C.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                lib().morna_index_destroy(h)
+            except Exception:
+                pass
+            self._h = C.c_void_p()
+
+    # ---- items -----------------------------------------------------------
+    def add_item(self, i, vector):
+        v = np.ascontiguousarray(vector, dtype=np.float64)
+        if v.shape != (self.f,):
+            raise IndexError("Vector has wrong length (expected %d, got %d)" % (self.f, v.size))
+        check(lib().morna_add_item(self._h, int(i), ptr(v)))
+
+    def add_items(self, rows, first_id=0):
+        """Bulk add_item for ids first_id.. (rows already fp32)."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.ndim != 2 or rows.shape[1] != self.f:
+            raise IndexError("rows must be [n, %d]" % self.f)
+        check(lib().morna_add_items_f32(self._h, int(first_id), ptr(rows), rows.shape[0]))
+
+    def get_n_items(self):
+        return int(lib().morna_get_n_items(self._h))
+
+    def get_item_vector(self, i):
+        out = np.empty(self.f, dtype=np.float32)
+        check(lib().morna_get_item_vector(self._h, int(i), ptr(out)))
+        return [float(x) for x in out]
+
+    def get_items(self):
+        out = np.empty((self.get_n_items(), self.f), dtype=np.float32)
+        check(lib().morna_get_items(self._h, ptr(out)))
+        return out
+
+    def get_norms2(self):
+        out = np.empty(self.get_n_items(), dtype=np.float32)
+        check(lib().morna_get_norms2(self._h, ptr(out)))
+        return out
+
+    # ---- fused feature build (MornaIndex uses this instead of add_item) ----
+    def stage_junctions(self, key_bytes, key_off, row_ptr, item_ids, cov, idf):
+        key_bytes = np.ascontiguousarray(key_bytes, dtype=np.uint8)
+        key_off = np.ascontiguousarray(key_off, dtype=np.int64)
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
+        item_ids = np.ascontiguousarray(item_ids, dtype=np.int32)
+        cov = np.ascontiguousarray(cov, dtype=np.int32)
+        idf = np.ascontiguousarray(idf, dtype=np.float64)
+        J = len(key_off) - 1
+        if len(row_ptr) != J + 1 or len(idf) != J or len(item_ids) != len(cov):
+            raise ValueError("stage_junctions: inconsistent array lengths")
+        check(lib().morna_stage_junctions(self._h, ptr(key_bytes), ptr(key_off), J, ptr(row_ptr),
+                                          ptr(item_ids), ptr(cov), ptr(idf)))
+
+    def build_features(self, n_items):
+        check(lib().morna_build_features(self._h, int(n_items)))
+
+    def unstage_junctions(self):
+        check(lib().morna_unstage_junctions(self._h))
+
+    def hash_keys(self, key_bytes, key_off):
+        key_bytes = np.ascontiguousarray(key_bytes, dtype=np.uint8)
+        key_off = np.ascontiguousarray(key_off, dtype=np.int64)
+        J = len(key_off) - 1
+        h = np.empty(J, np.int32)
+        col = np.empty(J, np.int32)
+        sign = np.empty(J, np.int32)
+        check(lib().morna_hash_keys(self._h, ptr(key_bytes), ptr(key_off), J, ptr(h), ptr(col), ptr(sign)))
+        return h, col, sign
+
+    # ---- forest ----------------------------------------------------------
+    def build(self, n_trees, seed=0):
+        check(lib().morna_build(self._h, int(n_trees), int(seed) & 0xFFFFFFFF))
+        return True
+
+    def get_n_trees(self):
+        return int(lib().morna_get_n_trees(self._h))
+
+    def forest_stats(self):
+        st = _lib.ForestStats()
+        check(lib().morna_get_forest_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def get_forest(self):
+        """dict(node_rec [n_nodes,6], perm [T,N], hyperplanes [n_split,f], hp_node [n_split])."""
+        st = self.forest_stats()
+        rec = np.empty((st["n_nodes"], 6), np.int32)
+        perm = np.empty((st["n_trees"], st["n_items"]), np.int32)
+        hp = np.empty((max(st["n_split"], 1), self.f), np.float32)
+        hp_node = np.empty(max(st["n_split"], 1), np.int32)
+        check(lib().morna_get_forest(self._h, ptr(rec), ptr(perm), ptr(hp), ptr(hp_node)))
+        return dict(node_rec=rec, perm=perm, hyperplanes=hp[:st["n_split"]], hp_node=hp_node[:st["n_split"]])
+
+    # ---- search ------------------------------------------------------------
+    def get_nns_by_vector_batch(self, Q, n, search_k=-1):
+        Q = np.ascontiguousarray(Q, dtype=np.float32)
+        if Q.ndim != 2 or Q.shape[1] != self.f:
+            raise IndexError("queries must be [nq, %d]" % self.f)
+        nq = Q.shape[0]
+        ids = np.empty((nq, n), np.int32)
+        d = np.empty((nq, n), np.float32)
+        cnt = np.empty(nq, np.int32)
+        check(lib().morna_get_nns_by_vector(self._h, ptr(Q), nq, int(n), int(search_k), ptr(ids), ptr(d), ptr(cnt)))
+        return ids, d, cnt
+
+    def get_nns_by_item_batch(self, items, n, search_k=-1):
+        items = np.ascontiguousarray(items, dtype=np.int32)
+        nq = items.shape[0]
+        ids = np.empty((nq, n), np.int32)
+        d = np.empty((nq, n), np.float32)
+        cnt = np.empty(nq, np.int32)
+        check(lib().morna_get_nns_by_item(self._h, ptr(items), nq, int(n), int(search_k), ptr(ids), ptr(d), ptr(cnt)))
+        return ids, d, cnt
+
+    def get_nns_by_vector(self, vector, n, search_k=-1, include_distances=False):
+        v = np.ascontiguousarray(vector, dtype=np.float32)   # annoy stores/queries fp32
+        if v.shape != (self.f,):
+            raise IndexError("Vector has wrong length (expected %d, got %d)" % (self.f, v.size))
+        ids, d, cnt = self.get_nns_by_vector_batch(v[None, :], n, search_k)
+        m = int(cnt[0])
+        out = [int(x) for x in ids[0, :m]]
+        if include_distances:
+            return out, [float(x) for x in d[0, :m]]
+        return out
+
+    def get_nns_by_item(self, i, n, search_k=-1, include_distances=False):
+        ids, d, cnt = self.get_nns_by_item_batch(np.array([i], np.int32), n, search_k)
+        m = int(cnt[0])
+        out = [int(x) for x in ids[0, :m]]
+        if include_distances:
+            return out, [float(x) for x in d[0, :m]]
+        return out
+
+    def exact_search_batch(self, Q, n):
+        """exact_search_nn (morna.py:681-716) for fp64 queries [nq, f]."""
+        Q = np.ascontiguousarray(Q, dtype=np.float64)
+        if Q.ndim != 2 or Q.shape[1] != self.f:
+            raise IndexError("queries must be [nq, %d]" % self.f)
+        nq = Q.shape[0]
+        ids = np.empty((nq, n), np.int32)
+        d = np.empty((nq, n), np.float64)
+        cnt = np.empty(nq, np.int32)
+        check(lib().morna_exact_search(self._h, ptr(Q), nq, int(n), ptr(ids), ptr(d), ptr(cnt)))
+        return ids, d, cnt
+
+    # ---- persistence ---------------------------------------------------------
+    def save(self, fn):
+        check(lib().morna_save(self._h, str(fn).encode()))
+        return True
+
+    def load(self, fn):
+        check(lib().morna_load(self._h, str(fn).encode()))
+        return True
+
+    # ---- measurement -----------------------------------------------------------
+    def timer_enable(self, on=True):
+        check(lib().morna_timer_enable(self._h, 1 if on else 0))
+
+    def timer_reset(self):
+        check(lib().morna_timer_reset(self._h))
+
+    def timers(self):
+        out = {}
+        for i, name in enumerate(_lib.TIMER_NAMES):
+            ms, n, b = C.c_double(0), C.c_int64(0), C.c_int64(0)
+            check(lib().morna_timer_read(self._h, i, C.byref(ms), C.byref(n), C.byref(b)))
+            out[name] = dict(ms=ms.value, launches=n.value, bytes=b.value)
+        return out
+
+    def synchronize(self):
+        check(lib().morna_synchronize(self._h))

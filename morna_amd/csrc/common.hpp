@@ -1,0 +1,173 @@
+// common.hpp -- shared declarations of libmorna_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/morna_hip.h"
+
+#define WAVE 64
+
+namespace morna {
+
+void set_error(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            morna::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                             __LINE__);                                                       \
+            return MORNA_E_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+#define MORNA_TRY(expr)            \
+    do {                           \
+        int _r = (expr);           \
+        if (_r != MORNA_OK) return _r; \
+    } while (0)
+
+// ---- device buffer with explicit lifetime -----------------------------------
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;  // elements
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    int alloc(size_t count)
+    {
+        if (count <= n && p) return MORNA_OK;
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+            return MORNA_E_HIP;
+        }
+        n = count;
+        return MORNA_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+// A node of the forest as the host driver tracks it (perm segment of one tree).
+struct Seg {
+    int32_t tree, level, start, count, node;
+};
+
+struct Timer {
+    double ms = 0;
+    int64_t launches = 0, bytes = 0;
+};
+
+// one timed launch group whose events have been recorded but not yet read
+struct PendingEv {
+    hipEvent_t a, b;
+    int which;
+    int64_t bytes;
+};
+
+}  // namespace morna
+
+struct morna_index {
+    int32_t dim = 0;     // D (f in annoy)
+    int32_t dpad = 0;    // row stride in floats: D rounded up to 32 (128-byte rows)
+    int32_t device = 0;
+    int32_t K = 0;       // leaf capacity D + 2
+    hipStream_t stream = nullptr;
+
+    // host staging of add_item() rows until build()
+    std::vector<float> host_rows;  // [host_n][dim]
+    int64_t host_n = 0;
+    bool host_dirty = false;
+
+    // items in HBM
+    int64_t n_items = 0;
+    morna::DevBuf<float> X;      // [n_items][dpad], pad columns zero
+    morna::DevBuf<float> norm2;  // [n_items] canonical dot(x, x)
+    bool norms_valid = false;
+
+    // staged junction lines (CSR by line, file order)
+    int64_t J = 0, nnz = 0, key_bytes_n = 0;
+    morna::DevBuf<uint8_t> s_keys;
+    morna::DevBuf<int64_t> s_key_off, s_row_ptr;
+    morna::DevBuf<int32_t> s_ids, s_cov;
+    morna::DevBuf<double> s_idf;
+    bool staged = false;
+
+    // forest
+    int32_t n_trees = 0;
+    uint32_t seed = 0;
+    bool built = false;
+    int64_t n_nodes = 0, n_split = 0;
+    morna::DevBuf<int32_t> perm;        // [n_trees][n_items]
+    morna::DevBuf<int32_t> node_rec;    // [n_nodes][4] {child0 | -1, child1 | -1, start, count}
+    morna::DevBuf<int32_t> node_tree;   // [n_nodes]
+    morna::DevBuf<int32_t> node_hp;     // [n_nodes] hyperplane slot or -1
+    morna::DevBuf<float> hp;            // [n_split][dpad]
+    morna_forest_stats stats = {};
+    std::vector<int32_t> h_node_rec, h_node_tree, h_node_hp;  // host mirrors
+
+    // query workspace (grown on demand)
+    morna::DevBuf<uint8_t> ws;
+    // [0] rows read by query kernels (hyperplane dots + candidates + 1 per query)
+    morna::DevBuf<unsigned long long> d_stat;
+
+    // timing
+    bool timing = false;
+    morna::Timer timers[MORNA_T_COUNT];
+    std::vector<morna::PendingEv> pending_ev;  // resolved by resolve_timers()
+    std::vector<hipEvent_t> free_ev;
+};
+
+namespace morna {
+
+// scope timer: records a HIP event pair on the handle's stream around a launch
+// group; no host synchronisation here, the pairs are read by resolve_timers().
+hipEvent_t take_event(morna_index *h);
+void resolve_timers(morna_index *h);
+struct ScopedTimer {
+    morna_index *h;
+    PendingEv pe;
+    ScopedTimer(morna_index *h_, int which, int64_t bytes) : h(h_)
+    {
+        pe.which = which;
+        pe.bytes = bytes;
+        pe.a = pe.b = nullptr;
+        if (!h->timing) return;
+        pe.a = take_event(h);
+        pe.b = take_event(h);
+        (void)hipEventRecord(pe.a, h->stream);
+    }
+    ~ScopedTimer()
+    {
+        if (!h->timing) return;
+        (void)hipEventRecord(pe.b, h->stream);
+        h->pending_ev.push_back(pe);
+    }
+};
+
+// implemented in features.hip / forest.hip / knn.hip
+int upload_host_rows(morna_index *h);
+int compute_norms(morna_index *h);
+int build_features(morna_index *h, int64_t n_items);
+int hash_keys_device(morna_index *h, const uint8_t *key_bytes, const int64_t *key_off, int64_t J,
+                     int32_t *hash_out, int32_t *col_out, int32_t *sign_out);
+int build_forest(morna_index *h, int32_t n_trees, uint32_t seed);
+int query_batch(morna_index *h, const float *q_host, const int32_t *items_host, int64_t nq, int32_t k,
+                int32_t search_k, int32_t *ids_out, float *dist_out, int32_t *count_out);
+int exact_search(morna_index *h, const double *q, int64_t nq, int32_t k, int32_t *ids_out,
+                 double *dist_out, int32_t *count_out);
+
+}  // namespace morna

@@ -1,0 +1,208 @@
+// devutil.hpp -- device-side building blocks shared by the kernels (gfx950, wave64).
+//
+// Arithmetic contract (DESIGN.md "Numerics"): everything the forest and the
+// approximate search compute is defined by
+//   * wave_dot(): the 64-lane canonical dot product -- lane l owns elements
+//     256*k + 4*l + c, one fmaf chain per c over k, folded (a0+a1)+(a2+a3),
+//     lanes combined by an xor butterfly 32,16,8,4,2,1;
+//   * ang_dist(): annoy's Angular::distance with its double literals;
+//   * Kiss32 streams seeded per (tree, level, segment start, attempt).
+// This file is compiled with -ffp-contract=off: a*b+c stays two roundings unless
+// written as fmaf.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace morna {
+
+// ---------------------------------------------------------------- hashing / RNG
+
+__host__ __device__ inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+__host__ __device__ inline uint32_t fmix32(uint32_t h)
+{
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+
+// MurmurHash3_x86_32 (what mmh3.hash computes, morna.py:369), unsigned result.
+__host__ __device__ inline uint32_t murmur3_32(const uint8_t *key, int64_t len, uint32_t seed)
+{
+    const uint32_t c1 = 0xcc9e2d51u, c2 = 0x1b873593u;
+    uint32_t h1 = seed;
+    const int64_t nblocks = len >> 2;
+    for (int64_t i = 0; i < nblocks; i++) {
+        const uint8_t *b = key + 4 * i;
+        uint32_t k1 = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+        k1 *= c1;
+        k1 = rotl32(k1, 15);
+        k1 *= c2;
+        h1 ^= k1;
+        h1 = rotl32(h1, 13);
+        h1 = h1 * 5u + 0xe6546b64u;
+    }
+    const uint8_t *tail = key + nblocks * 4;
+    uint32_t k1 = 0;
+    const int rem = (int)(len & 3);
+    if (rem == 3) k1 ^= (uint32_t)tail[2] << 16;
+    if (rem >= 2) k1 ^= (uint32_t)tail[1] << 8;
+    if (rem >= 1) {
+        k1 ^= tail[0];
+        k1 *= c1;
+        k1 = rotl32(k1, 15);
+        k1 *= c2;
+        h1 ^= k1;
+    }
+    h1 ^= (uint32_t)len;
+    return fmix32(h1);
+}
+
+// Python's floored `h % dim` for dim > 0 (morna.py:371).
+__host__ __device__ inline int32_t floored_mod(int32_t h, int32_t dim)
+{
+    int32_t r = h % dim;
+    return r < 0 ? r + dim : r;
+}
+
+// annoy's Kiss32Random
+struct Kiss32 {
+    uint32_t x, y, z, c;
+    __host__ __device__ explicit Kiss32(uint32_t seed) : x(seed), y(362436000u), z(521288629u), c(7654321u) {}
+    __host__ __device__ inline uint32_t next()
+    {
+        x = 69069u * x + 12345u;
+        y ^= y << 13;
+        y ^= y >> 17;
+        y ^= y << 5;
+        uint64_t t = 698769069ULL * z + c;
+        c = (uint32_t)(t >> 32);
+        z = (uint32_t)t;
+        return x + y + z;
+    }
+    __host__ __device__ inline uint32_t index(uint32_t n) { return next() % n; }
+};
+
+// seed of the stream owned by one split attempt of one node
+__host__ __device__ inline uint32_t node_seed(uint32_t seed, uint32_t tree, uint32_t level, uint32_t start,
+                                              uint32_t attempt)
+{
+    uint32_t h = fmix32(seed + 0x9E3779B9u * (tree + 1u));
+    h = fmix32(h ^ (level * 0x85ebca6bu + 0x27d4eb2fu));
+    h = fmix32(h ^ start);
+    h = fmix32(h + attempt * 0xc2b2ae35u + 0x165667b1u);
+    return h ? h : 1u;
+}
+
+// coin flip for the item at position i of the node's segment (margin == 0, fallback)
+__host__ __device__ inline int pos_flip(uint32_t nseed, uint32_t i)
+{
+    return (int)(fmix32(nseed ^ fmix32(i + 0x632BE5ABu)) & 1u);
+}
+
+// annoy's _split_imbalance
+__host__ __device__ inline double split_imbalance(int64_t left, int64_t right)
+{
+    double ls = (float)left, rs = (float)right;
+    float f = (float)(ls / (ls + rs + 1e-9));
+    return f > 1 - f ? f : 1 - f;
+}
+
+// ------------------------------------------------------------------- arithmetic
+
+// Angular::distance, T = float fields with double literals.
+__device__ inline float ang_dist(float pp, float qq, float pq)
+{
+    float ppqq = pp * qq;
+    if (ppqq > 0) return (float)(2.0 - 2.0 * (double)pq / (double)sqrtf(ppqq));
+    return 2.0f;
+}
+
+// order-preserving map float -> uint32 (total order of non-NaN values)
+__device__ inline uint32_t f32_orderable(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline float f32_from_orderable(uint32_t u)
+{
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__device__ inline float wave_sum_xor(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, WAVE);
+    return v;
+}
+
+// fold of the four per-lane chains, then the butterfly
+__device__ inline float wave_dot_finish(float a0, float a1, float a2, float a3)
+{
+    return wave_sum_xor((a0 + a1) + (a2 + a3));
+}
+
+#define FMA4(acc, xv, yv)                         \
+    do {                                          \
+        acc##0 = __builtin_fmaf(xv.x, yv.x, acc##0); \
+        acc##1 = __builtin_fmaf(xv.y, yv.y, acc##1); \
+        acc##2 = __builtin_fmaf(xv.z, yv.z, acc##2); \
+        acc##3 = __builtin_fmaf(xv.w, yv.w, acc##3); \
+    } while (0)
+
+// Canonical dot of two vectors of nvec float4 (both 16-byte aligned, zero padded
+// to a multiple of 4 floats).  All 64 lanes of the wave must call it; every lane
+// receives the result.  a and b may be in any address space the compiler can
+// resolve (global rows, LDS images).
+template <typename PA, typename PB>
+__device__ inline float wave_dot(PA a, PB b, int nvec, int lane)
+{
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = lane;
+    // 4 independent 1-KiB loads in flight per operand before the first use
+    for (; i + 3 * WAVE < nvec; i += 4 * WAVE) {
+        float4 x0 = a[i], x1 = a[i + WAVE], x2 = a[i + 2 * WAVE], x3 = a[i + 3 * WAVE];
+        float4 y0 = b[i], y1 = b[i + WAVE], y2 = b[i + 2 * WAVE], y3 = b[i + 3 * WAVE];
+        FMA4(s, x0, y0);
+        FMA4(s, x1, y1);
+        FMA4(s, x2, y2);
+        FMA4(s, x3, y3);
+    }
+    for (; i < nvec; i += WAVE) {
+        float4 x = a[i], y = b[i];
+        FMA4(s, x, y);
+    }
+    return wave_dot_finish(s0, s1, s2, s3);
+}
+
+// 64-bit butterfly helpers for (key) reductions
+__device__ inline uint64_t shfl_xor_u64(uint64_t v, int off)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_xor(lo, off, WAVE);
+    hi = __shfl_xor(hi, off, WAVE);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ inline uint64_t wave_min_u64(uint64_t v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint64_t o = shfl_xor_u64(v, off);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ inline uint64_t wave_max_u64(uint64_t v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint64_t o = shfl_xor_u64(v, off);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+}  // namespace morna

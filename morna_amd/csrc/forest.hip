@@ -1,0 +1,545 @@
+// forest.hip -- level-synchronous random-projection forest build on gfx950.
+//
+// Replaces AnnoyIndex.build(n_trees) (reference call site morna.py:425; the
+// algorithm is spotify/annoy's _make_tree / two_means / Angular::create_split,
+// restated in oracle/annoy_oracle.c mode 1 and SURVEY.md section 2.1).
+//
+// All n_trees trees advance one level per round.  A tree is a permutation of the
+// item ids (perm[tree][N]); a node is a contiguous segment of it.  Per level:
+//   two_means_kernel  one workgroup per split node: 200 sequential centroid
+//                     updates on LDS-resident centroids, rows prefetched one
+//                     iteration ahead (the Kiss32 stream does not depend on data)
+//   split_kernel      THE bandwidth kernel: every row of every split node is
+//                     streamed once from HBM and dotted (wavefront dot product,
+//                     hyperplane resident in LDS) against its node's hyperplane;
+//                     lane 0 records the side, one integer atomic per workgroup
+//                     counts the right-hand rows
+//   (host)            annoy's 3-attempt / 0.95 imbalance rule on the counts
+//   fallback_kernel   random sides for nodes still above 0.99
+//   partition_kernel  stable partition of each segment by side
+// Node ids are handed out breadth-first, children of the i-th split node of a
+// level get consecutive ids, exactly as oracle mode 1 does.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+#include "devutil.hpp"
+
+namespace morna {
+
+// one split attempt of one node, as the kernels see it
+struct SplitTask {
+    int32_t tree, level, start, count;
+    int32_t slot;      // hyperplane slot
+    int32_t attempt;
+    int32_t chunk0;    // first chunk index of this task in the split kernel grid
+    int32_t pad;
+};
+
+#define TM_THREADS 256
+#define TM_ITERS 200
+
+// ------------------------------------------------------------------ two_means
+
+// normalise an LDS vector in place: v /= sqrt(dot(v, v)) when the norm is > 0
+__device__ inline void lds_normalize(float *v, int dpad, int tid, int lane, int w, float *s_tmp)
+{
+    if (w == 0) {
+        float n2 = wave_dot((const float4 *)v, (const float4 *)v, dpad / 4, lane);
+        if (lane == 0) s_tmp[0] = sqrtf(n2);
+    }
+    __syncthreads();
+    const float norm = s_tmp[0];
+    if (norm > 0.f)
+        for (int z = tid; z < dpad; z += TM_THREADS) v[z] = v[z] / norm;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(TM_THREADS) void two_means_kernel(const float *__restrict__ X,
+                                                               const float *__restrict__ norm2, int64_t n_items,
+                                                               int32_t dpad, const int32_t *__restrict__ perm,
+                                                               const SplitTask *__restrict__ tasks, uint32_t seed,
+                                                               float *__restrict__ hp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *p = (float *)smem;        // centroid p   [dpad]
+    float *q = p + dpad;             // centroid q   [dpad]
+    float *xs = q + dpad;            // current row  [dpad]
+    __shared__ float s_tmp[4];       // 0: scratch norm, 1: pp, 2: qq
+    __shared__ float s_pq[2];
+
+    const SplitTask t = tasks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int nvec = dpad / 4;
+    const int32_t *items = perm + (int64_t)t.tree * n_items + t.start;
+    Kiss32 rng(node_seed(seed, (uint32_t)t.tree, (uint32_t)t.level, (uint32_t)t.start, (uint32_t)t.attempt));
+
+    // two distinct random items seed the centroids
+    uint32_t i = rng.index((uint32_t)t.count);
+    uint32_t j = rng.index((uint32_t)t.count - 1u);
+    j += (j >= i);
+    {
+        const float4 *xi = (const float4 *)(X + (int64_t)items[i] * dpad);
+        const float4 *xj = (const float4 *)(X + (int64_t)items[j] * dpad);
+        for (int v = tid; v < nvec; v += TM_THREADS) {
+            ((float4 *)p)[v] = xi[v];
+            ((float4 *)q)[v] = xj[v];
+        }
+    }
+    __syncthreads();
+    lds_normalize(p, dpad, tid, lane, w, s_tmp);
+    lds_normalize(q, dpad, tid, lane, w, s_tmp);
+    if (w == 0) {
+        float v = wave_dot((const float4 *)p, (const float4 *)p, nvec, lane);
+        if (lane == 0) s_tmp[1] = v;
+    } else if (w == 1) {
+        float v = wave_dot((const float4 *)q, (const float4 *)q, nvec, lane);
+        if (lane == 0) s_tmp[2] = v;
+    }
+    // first row of the loop
+    uint32_t k = rng.index((uint32_t)t.count);
+    int32_t it = items[k];
+    {
+        const float4 *xk = (const float4 *)(X + (int64_t)it * dpad);
+        for (int v = tid; v < nvec; v += TM_THREADS) ((float4 *)xs)[v] = xk[v];
+    }
+    __syncthreads();
+
+    int ic = 1, jc = 1;
+    // registers for the prefetched next row: nvec / 256 float4 per thread (<= 8 for D <= 8192)
+    constexpr int PF = 8;
+    for (int l = 0; l < TM_ITERS; l++) {
+        // prefetch row l+1 while row l is being used
+        uint32_t k_next = 0;
+        int32_t it_next = 0;
+        float4 pf[PF];
+#pragma unroll
+        for (int u = 0; u < PF; u++) pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool more = l + 1 < TM_ITERS;
+        if (more) {
+            k_next = rng.index((uint32_t)t.count);
+            it_next = items[k_next];
+            const float4 *xn = (const float4 *)(X + (int64_t)it_next * dpad);
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const int v = tid + u * TM_THREADS;
+                if (v < nvec) pf[u] = xn[v];
+            }
+        }
+        const float nk2 = norm2[it];
+        if (w == 0) {
+            float v = wave_dot((const float4 *)p, (const float4 *)xs, nvec, lane);
+            if (lane == 0) s_pq[0] = v;
+        } else if (w == 1) {
+            float v = wave_dot((const float4 *)q, (const float4 *)xs, nvec, lane);
+            if (lane == 0) s_pq[1] = v;
+        }
+        __syncthreads();
+        const float di = (float)ic * ang_dist(s_tmp[1], nk2, s_pq[0]);
+        const float dj = (float)jc * ang_dist(s_tmp[2], nk2, s_pq[1]);
+        const float norm = sqrtf(nk2);
+        if (norm > 0.f) {
+            if (di < dj) {
+                const float fic = (float)ic, fic1 = (float)(ic + 1);
+                for (int z = tid; z < dpad; z += TM_THREADS) p[z] = (p[z] * fic + xs[z] / norm) / fic1;
+                __syncthreads();
+                if (w == 0) {
+                    float v = wave_dot((const float4 *)p, (const float4 *)p, nvec, lane);
+                    if (lane == 0) s_tmp[1] = v;
+                }
+                ic++;
+            } else if (dj < di) {
+                const float fjc = (float)jc, fjc1 = (float)(jc + 1);
+                for (int z = tid; z < dpad; z += TM_THREADS) q[z] = (q[z] * fjc + xs[z] / norm) / fjc1;
+                __syncthreads();
+                if (w == 0) {
+                    float v = wave_dot((const float4 *)q, (const float4 *)q, nvec, lane);
+                    if (lane == 0) s_tmp[2] = v;
+                }
+                jc++;
+            }
+        }
+        __syncthreads();   // everyone is done with xs (and sees the new pp / qq)
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                int v = tid + u * TM_THREADS;
+                if (v < nvec) ((float4 *)xs)[v] = pf[u];
+            }
+            it = it_next;
+        }
+        __syncthreads();
+    }
+    // create_split: n = normalize(p - q)
+    for (int z = tid; z < dpad; z += TM_THREADS) p[z] = p[z] - q[z];
+    __syncthreads();
+    lds_normalize(p, dpad, tid, lane, w, s_tmp);
+    float4 *out = (float4 *)(hp + (int64_t)t.slot * dpad);
+    for (int v = tid; v < nvec; v += TM_THREADS) out[v] = ((float4 *)p)[v];
+}
+
+// ---------------------------------------------------------------- split kernel
+
+#define SP_THREADS 256
+#define SP_WAVES (SP_THREADS / WAVE)
+#define SP_ROWS 64      // rows per workgroup
+
+// rows of task `ti` at positions [chunk*SP_ROWS, ...) get their side
+__global__ __launch_bounds__(SP_THREADS) void split_kernel(const float *__restrict__ X, int64_t n_items, int32_t dpad,
+                                                           const int32_t *__restrict__ perm,
+                                                           const SplitTask *__restrict__ tasks, int32_t n_tasks,
+                                                           uint32_t seed, const float *__restrict__ hp,
+                                                           uint8_t *__restrict__ side, int32_t *__restrict__ ones)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *hs = (float4 *)smem;   // hyperplane [dpad]
+    __shared__ int s_ones;
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int nvec = dpad / 4;
+    // find the task owning this chunk (tasks sorted by chunk0)
+    int lo = 0, hi = n_tasks - 1;
+    const int chunk = blockIdx.x;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (tasks[mid].chunk0 <= chunk) lo = mid; else hi = mid - 1;
+    }
+    const SplitTask t = tasks[lo];
+    const int pos0 = (chunk - t.chunk0) * SP_ROWS;
+    const int nrows = (t.count - pos0) < SP_ROWS ? (t.count - pos0) : SP_ROWS;
+
+    const float4 *hsrc = (const float4 *)(hp + (int64_t)t.slot * dpad);
+    for (int v = tid; v < nvec; v += SP_THREADS) hs[v] = hsrc[v];
+    if (tid == 0) s_ones = 0;
+    __syncthreads();
+
+    const int32_t *items = perm + (int64_t)t.tree * n_items + t.start + pos0;
+    uint8_t *sd = side + (int64_t)t.tree * n_items + t.start + pos0;
+    const uint32_t nseed = node_seed(seed, (uint32_t)t.tree, (uint32_t)t.level, (uint32_t)t.start, (uint32_t)t.attempt);
+    int my_ones = 0;
+    for (int r = w; r < nrows; r += SP_WAVES) {
+        const float4 *x = (const float4 *)(X + (int64_t)items[r] * dpad);
+        const float d = wave_dot(x, hs, nvec, lane);
+        // Angular::side: dot != 0 ? dot > 0 : coin flip
+        const int s = d != 0.f ? (d > 0.f) : pos_flip(nseed, (uint32_t)(pos0 + r));
+        if (lane == 0) sd[r] = (uint8_t)s;
+        my_ones += s;
+    }
+    if (lane == 0 && my_ones) atomicAdd(&s_ones, my_ones);
+    __syncthreads();
+    if (tid == 0 && s_ones) atomicAdd(&ones[lo], s_ones);
+}
+
+// random sides for nodes whose best split is still > 0.99 imbalanced
+__global__ __launch_bounds__(256) void fallback_kernel(const SplitTask *__restrict__ tasks, int64_t n_items,
+                                                       int32_t dpad, uint32_t seed, uint8_t *__restrict__ side,
+                                                       int32_t *__restrict__ ones, float *__restrict__ hp)
+{
+    __shared__ int s_cnt;
+    const SplitTask t = tasks[blockIdx.x];
+    const int tid = threadIdx.x;
+    uint8_t *sd = side + (int64_t)t.tree * n_items + t.start;
+    for (int z = tid; z < dpad; z += 256) hp[(int64_t)t.slot * dpad + z] = 0.f;   // m->v = 0
+    for (int round = 0;; round++) {
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        int mine = 0;
+        if (round >= 32) {   // give up on chance: halve by position
+            for (int p = tid; p < t.count; p += 256) {
+                int s = p >= t.count / 2;
+                sd[p] = (uint8_t)s;
+                mine += s;
+            }
+        } else {
+            const uint32_t ns = node_seed(seed, (uint32_t)t.tree, (uint32_t)t.level, (uint32_t)t.start, (uint32_t)(3 + round));
+            for (int p = tid; p < t.count; p += 256) {
+                int s = pos_flip(ns, (uint32_t)p);
+                sd[p] = (uint8_t)s;
+                mine += s;
+            }
+        }
+        if (mine) atomicAdd(&s_cnt, mine);
+        __syncthreads();
+        const int n1 = s_cnt;
+        __syncthreads();
+        if (round >= 32 || !(split_imbalance(t.count - n1, n1) > 0.99)) {
+            if (tid == 0) ones[blockIdx.x] = n1;
+            break;
+        }
+    }
+}
+
+// stable partition of one segment by side; one workgroup per node
+__global__ __launch_bounds__(256) void partition_kernel(const SplitTask *__restrict__ tasks, int64_t n_items,
+                                                        const uint8_t *__restrict__ side,
+                                                        const int32_t *__restrict__ ones, int32_t *__restrict__ perm,
+                                                        int32_t *__restrict__ tmp)
+{
+    __shared__ int s_w1[4];
+    const SplitTask t = tasks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int n1 = ones[blockIdx.x], n0 = t.count - n1;
+    const int64_t base = (int64_t)t.tree * n_items + t.start;
+    int run0 = 0, run1 = 0;   // items already placed on each side
+    for (int p0 = 0; p0 < t.count; p0 += 256) {
+        const int p = p0 + tid;
+        const bool valid = p < t.count;
+        const int s = valid ? side[base + p] : 0;
+        const unsigned long long b1 = __ballot(valid && s);
+        const unsigned long long bv = __ballot(valid);
+        if (lane == 0) s_w1[w] = __popcll(b1);
+        __syncthreads();
+        int ones_before = 0, ones_tile = 0, valid_before = w * WAVE;   // full waves precede a partial one
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (i < w) ones_before += s_w1[i];
+            ones_tile += s_w1[i];
+        }
+        const unsigned long long lower = (1ull << lane) - 1ull;
+        const int r1 = ones_before + __popcll(b1 & lower);
+        const int rv = valid_before + __popcll(bv & lower);
+        if (valid) {
+            const int dst = s ? (n0 + run1 + r1) : (run0 + (rv - r1));
+            tmp[base + dst] = perm[base + p];
+        }
+        const int tile_valid = (t.count - p0) < 256 ? (t.count - p0) : 256;
+        run1 += ones_tile;
+        run0 += tile_valid - ones_tile;
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int p = tid; p < t.count; p += 256) perm[base + p] = tmp[base + p];
+}
+
+__global__ void iota_perm_kernel(int32_t *perm, int64_t n_items, int64_t total)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) perm[i] = (int32_t)(i % n_items);
+}
+
+// -------------------------------------------------------------- host driver
+
+int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
+{
+    MORNA_TRY(upload_host_rows(h));
+    if (h->n_items <= 0) {
+        set_error("no items were added to the index before build()");
+        return MORNA_E_EMPTY;
+    }
+    if (n_trees <= 0) {
+        set_error("build: n_trees must be positive (annoy's q = -1 auto mode is not used by morna)");
+        return MORNA_E_INVALID;
+    }
+    if (!h->norms_valid) MORNA_TRY(compute_norms(h));
+    if (seed == 0) seed = 123456789u;   // Kiss32Random's default seed
+    const int64_t N = h->n_items;
+    const int32_t dpad = h->dpad, K = h->K, D = h->dim;
+    if (dpad > 8192) {   // two_means prefetches a row in 8 float4 per thread; 3 rows of LDS
+        set_error("build: dimension %d is above the supported 8192", D);
+        return MORNA_E_INVALID;
+    }
+    h->built = false;
+    h->n_trees = n_trees;
+    h->seed = seed;
+    h->stats = morna_forest_stats();
+    h->stats.n_items = N;
+    h->stats.dim = D;
+    h->stats.leaf_capacity = K;
+    h->stats.n_trees = n_trees;
+
+    MORNA_TRY(h->perm.alloc((size_t)n_trees * N));
+    DevBuf<int32_t> tmp, d_ones;
+    DevBuf<uint8_t> side;
+    DevBuf<SplitTask> d_tasks;
+    MORNA_TRY(tmp.alloc((size_t)n_trees * N));
+    MORNA_TRY(side.alloc((size_t)n_trees * N));
+    {
+        const int64_t total = (int64_t)n_trees * N;
+        hipLaunchKernelGGL(iota_perm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->perm.p, N, total);
+        HIP_TRY(hipGetLastError());
+    }
+
+    // host-side node table, breadth-first ids; roots are 0..T-1
+    std::vector<int32_t> &rec = h->h_node_rec, &ntree = h->h_node_tree, &nhp = h->h_node_hp;
+    rec.clear(); ntree.clear(); nhp.clear();
+    std::vector<Seg> cur((size_t)n_trees), nxt;
+    for (int t = 0; t < n_trees; t++) {
+        cur[(size_t)t] = Seg{t, 0, 0, (int32_t)N, t};
+        rec.insert(rec.end(), {-1, -1, 0, (int32_t)N});
+        ntree.push_back(t);
+        nhp.push_back(-1);
+    }
+    // hyperplanes are produced level by level into growing storage
+    std::vector<float *> level_hp;          // device buffers, one per level
+    std::vector<int32_t> level_hp_count;
+    int64_t n_split_total = 0;
+    int rc = MORNA_OK;
+    std::vector<SplitTask> tasks, pend;
+    std::vector<int32_t> h_ones;
+    int32_t level = 0;
+
+    auto cleanup = [&]() {
+        for (float *p : level_hp) (void)hipFree(p);
+        level_hp.clear();
+    };
+#define F_TRY(e)                                                    \
+    do {                                                            \
+        hipError_t _e = (e);                                        \
+        if (_e != hipSuccess) {                                     \
+            set_error("%s failed: %s", #e, hipGetErrorString(_e));  \
+            cleanup();                                              \
+            return MORNA_E_HIP;                                     \
+        }                                                           \
+    } while (0)
+
+    while (!cur.empty()) {
+        // split nodes of this level, in cur order
+        std::vector<int32_t> split_idx;
+        for (size_t i = 0; i < cur.size(); i++)
+            if (cur[i].count > K) split_idx.push_back((int32_t)i);
+        h->stats.max_depth = std::max<int64_t>(h->stats.max_depth, level);
+        if (split_idx.empty()) break;
+        const int32_t S = (int32_t)split_idx.size();
+        float *hp_level = nullptr;
+        F_TRY(hipMalloc((void **)&hp_level, (size_t)S * dpad * sizeof(float)));
+        level_hp.push_back(hp_level);
+        level_hp_count.push_back(S);
+
+        // final outcome per split node of this level
+        std::vector<int32_t> final_ones((size_t)S, 0);
+        std::vector<int32_t> pending((size_t)S);
+        for (int32_t i = 0; i < S; i++) pending[(size_t)i] = i;
+        if ((rc = d_tasks.alloc((size_t)S)) || (rc = d_ones.alloc((size_t)S))) { cleanup(); return rc; }
+
+        auto make_tasks = [&](const std::vector<int32_t> &which, int attempt, std::vector<SplitTask> &out) {
+            out.resize(which.size());
+            int32_t chunk = 0;
+            for (size_t a = 0; a < which.size(); a++) {
+                const Seg &s = cur[(size_t)split_idx[(size_t)which[a]]];
+                out[a] = SplitTask{s.tree, s.level, s.start, s.count, which[a], attempt, chunk, 0};
+                chunk += (s.count + SP_ROWS - 1) / SP_ROWS;
+            }
+            return chunk;
+        };
+
+        for (int attempt = 0; attempt < 3 && !pending.empty(); attempt++) {
+            const int32_t n_chunks = make_tasks(pending, attempt, tasks);
+            const int32_t A = (int32_t)tasks.size();
+            int64_t rows = 0;
+            for (const SplitTask &t : tasks) rows += t.count;
+            F_TRY(hipMemcpyAsync(d_tasks.p, tasks.data(), (size_t)A * sizeof(SplitTask), hipMemcpyHostToDevice, h->stream));
+            F_TRY(hipMemsetAsync(d_ones.p, 0, (size_t)A * 4, h->stream));
+            {
+                ScopedTimer tm(h, MORNA_T_TWO_MEANS, 4 * (int64_t)D * (TM_ITERS + 2) * A);
+                hipLaunchKernelGGL(two_means_kernel, dim3((unsigned)A), dim3(TM_THREADS), (size_t)dpad * 4 * 3, h->stream,
+                                   h->X.p, h->norm2.p, N, dpad, h->perm.p, d_tasks.p, seed, hp_level);
+            }
+            {
+                // algorithmic bytes: 4*D*sum|node| + 4*D*#split nodes
+                ScopedTimer tm(h, MORNA_T_SPLIT, 4 * (int64_t)D * (rows + A));
+                hipLaunchKernelGGL(split_kernel, dim3((unsigned)n_chunks), dim3(SP_THREADS), (size_t)dpad * 4, h->stream,
+                                   h->X.p, N, dpad, h->perm.p, d_tasks.p, A, seed, hp_level, side.p, d_ones.p);
+            }
+            F_TRY(hipGetLastError());
+            h_ones.resize((size_t)A);
+            F_TRY(hipMemcpyAsync(h_ones.data(), d_ones.p, (size_t)A * 4, hipMemcpyDeviceToHost, h->stream));
+            F_TRY(hipStreamSynchronize(h->stream));
+            h->stats.split_attempts += A;
+            h->stats.split_rows += rows;
+            std::vector<int32_t> still;
+            for (int32_t a = 0; a < A; a++) {
+                const int32_t i = pending[(size_t)a];
+                final_ones[(size_t)i] = h_ones[(size_t)a];
+                const int64_t n1 = h_ones[(size_t)a], n0 = tasks[(size_t)a].count - n1;
+                if (!(split_imbalance(n0, n1) < 0.95)) still.push_back(i);
+            }
+            pending.swap(still);
+        }
+        // "If we didn't find a hyperplane, just randomize sides as a last option"
+        std::vector<int32_t> fb;
+        for (int32_t i : pending) {
+            const int64_t n1 = final_ones[(size_t)i], n0 = cur[(size_t)split_idx[(size_t)i]].count - n1;
+            if (split_imbalance(n0, n1) > 0.99) fb.push_back(i);
+        }
+        if (!fb.empty()) {
+            make_tasks(fb, 3, tasks);
+            const int32_t A = (int32_t)tasks.size();
+            F_TRY(hipMemcpyAsync(d_tasks.p, tasks.data(), (size_t)A * sizeof(SplitTask), hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(fallback_kernel, dim3((unsigned)A), dim3(256), 0, h->stream, d_tasks.p, N, dpad, seed,
+                               side.p, d_ones.p, hp_level);
+            F_TRY(hipGetLastError());
+            h_ones.resize((size_t)A);
+            F_TRY(hipMemcpyAsync(h_ones.data(), d_ones.p, (size_t)A * 4, hipMemcpyDeviceToHost, h->stream));
+            F_TRY(hipStreamSynchronize(h->stream));
+            for (int32_t a = 0; a < A; a++) final_ones[(size_t)fb[(size_t)a]] = h_ones[(size_t)a];
+            h->stats.fallback_nodes += A;
+        }
+        // partition every split node of the level
+        {
+            std::vector<int32_t> all((size_t)S);
+            for (int32_t i = 0; i < S; i++) all[(size_t)i] = i;
+            make_tasks(all, 0, tasks);
+            F_TRY(hipMemcpyAsync(d_tasks.p, tasks.data(), (size_t)S * sizeof(SplitTask), hipMemcpyHostToDevice, h->stream));
+            F_TRY(hipMemcpyAsync(d_ones.p, final_ones.data(), (size_t)S * 4, hipMemcpyHostToDevice, h->stream));
+            ScopedTimer tm(h, MORNA_T_PARTITION, 0);
+            hipLaunchKernelGGL(partition_kernel, dim3((unsigned)S), dim3(256), 0, h->stream, d_tasks.p, N, side.p,
+                               d_ones.p, h->perm.p, tmp.p);
+        }
+        F_TRY(hipGetLastError());
+        F_TRY(hipStreamSynchronize(h->stream));   // tasks / final_ones host buffers are reused next level
+
+        // children: ids base + 2*i + side for the i-th split node of the level
+        nxt.clear();
+        for (int32_t i = 0; i < S; i++) {
+            const Seg &s = cur[(size_t)split_idx[(size_t)i]];
+            const int32_t n1 = final_ones[(size_t)i], n0 = s.count - n1;
+            const int32_t id0 = (int32_t)ntree.size(), id1 = id0 + 1;
+            rec[(size_t)s.node * 4 + 0] = id0;
+            rec[(size_t)s.node * 4 + 1] = id1;
+            nhp[(size_t)s.node] = (int32_t)(n_split_total + i);
+            rec.insert(rec.end(), {-1, -1, s.start, n0});
+            rec.insert(rec.end(), {-1, -1, s.start + n0, n1});
+            ntree.push_back(s.tree);
+            ntree.push_back(s.tree);
+            nhp.push_back(-1);
+            nhp.push_back(-1);
+            nxt.push_back(Seg{s.tree, s.level + 1, s.start, n0, id0});
+            nxt.push_back(Seg{s.tree, s.level + 1, s.start + n0, n1, id1});
+        }
+        n_split_total += S;
+        cur.swap(nxt);
+        level++;
+    }
+
+    // consolidate hyperplanes and node tables in HBM
+    h->n_split = n_split_total;
+    h->n_nodes = (int64_t)ntree.size();
+    if ((rc = h->hp.alloc((size_t)std::max<int64_t>(n_split_total, 1) * dpad))) { cleanup(); return rc; }
+    {
+        int64_t off = 0;
+        for (size_t l = 0; l < level_hp.size(); l++) {
+            F_TRY(hipMemcpyAsync(h->hp.p + off * dpad, level_hp[l], (size_t)level_hp_count[l] * dpad * 4,
+                                 hipMemcpyDeviceToDevice, h->stream));
+            off += level_hp_count[l];
+        }
+    }
+    if ((rc = h->node_rec.alloc(rec.size())) || (rc = h->node_tree.alloc(ntree.size())) || (rc = h->node_hp.alloc(nhp.size()))) {
+        cleanup();
+        return rc;
+    }
+    F_TRY(hipMemcpyAsync(h->node_rec.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice, h->stream));
+    F_TRY(hipMemcpyAsync(h->node_tree.p, ntree.data(), ntree.size() * 4, hipMemcpyHostToDevice, h->stream));
+    F_TRY(hipMemcpyAsync(h->node_hp.p, nhp.data(), nhp.size() * 4, hipMemcpyHostToDevice, h->stream));
+    F_TRY(hipStreamSynchronize(h->stream));
+    cleanup();
+#undef F_TRY
+    h->stats.n_nodes = h->n_nodes;
+    h->stats.n_split = h->n_split;
+    h->stats.n_leaves = h->n_nodes - h->n_split;
+    h->built = true;
+    return MORNA_OK;
+}
+
+}  // namespace morna

@@ -1,0 +1,541 @@
+// knn.hip -- batched nearest-neighbour queries on gfx950.
+//
+// query_kernel   : annoy's _get_all_nns (get_nns_by_vector / get_nns_by_item,
+//                  reference call sites morna.py:651, 659, 762, 769) -- one
+//                  workgroup per query fuses the best-first forest traversal
+//                  with the brute-force angular refine of the candidate rows and
+//                  the (distance, id) top-k selection.
+// exact_*_kernel : MornaSearch.exact_search_nn + cosine_distance (morna.py:
+//                  681-716, 101-114) -- an fp32 scan of all rows picks every row
+//                  that can be in the top k, then those rows are re-evaluated in
+//                  the reference's sequential fp64 order and ranked with the
+//                  bisect_left tie rule, so ids and distances are bit-exact.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "common.hpp"
+#include "devutil.hpp"
+
+namespace morna {
+
+#define Q_THREADS 256
+#define Q_WAVES (Q_THREADS / WAVE)
+
+struct QueryParams {
+    const float *X;
+    const float *norm2;
+    int64_t n_items;
+    int32_t dpad, n_trees, K;
+    const int32_t *node_rec;   // [n_nodes][4] child0, child1, start, count
+    const int32_t *node_tree;
+    const int32_t *node_hp;
+    const float *hp;
+    const int32_t *perm;
+    int64_t n_nodes;
+    const float *Q;            // [nq][dpad] or null
+    const int32_t *items;      // [nq] or null
+    int32_t k, search_k;
+    int32_t cap;               // candidate capacity per query
+    int32_t bm_words;
+    // workspace, one slice per query
+    uint64_t *pq;              // [nq][n_nodes]
+    int32_t *cand;             // [nq][cap]
+    uint64_t *keys;            // [nq][cap]
+    uint32_t *bm_global;       // [nq][bm_words] when the bitmap does not fit LDS
+    int32_t *ids_out;          // [nq][k]
+    float *dist_out;           // [nq][k]
+    int32_t *count_out;        // [nq]
+    unsigned long long *stat;  // rows read: hyperplane dots + unique candidates + query
+};
+
+__device__ inline uint64_t pq_key(float d, int32_t node)
+{
+    return ((uint64_t)f32_orderable(d) << 32) | (uint32_t)node;
+}
+
+// block-wide min of a uint64 (all threads get the result)
+__device__ inline uint64_t block_min_u64(uint64_t v, uint64_t *s_red, int tid)
+{
+    v = wave_min_u64(v);
+    __syncthreads();
+    if ((tid & (WAVE - 1)) == 0) s_red[tid / WAVE] = v;
+    __syncthreads();
+    uint64_t r = s_red[0];
+#pragma unroll
+    for (int i = 1; i < Q_WAVES; i++) r = s_red[i] < r ? s_red[i] : r;
+    return r;
+}
+
+template <bool BM_LDS>
+__global__ __launch_bounds__(Q_THREADS) void query_kernel(QueryParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *qv = (float4 *)smem;
+    uint32_t *bm = BM_LDS ? (uint32_t *)(smem + (size_t)P.dpad * sizeof(float))
+                          : P.bm_global + (size_t)blockIdx.x * P.bm_words;
+    __shared__ uint64_t s_red[Q_WAVES];
+    __shared__ int s_ncand;
+    __shared__ float s_pp;
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int64_t qi = blockIdx.x;
+    const int nvec = P.dpad / 4;
+    const int T = P.n_trees;
+
+    const float4 *src = P.items ? (const float4 *)(P.X + (int64_t)P.items[qi] * P.dpad)
+                                : (const float4 *)(P.Q + qi * P.dpad);
+    for (int i = tid; i < nvec; i += Q_THREADS) qv[i] = src[i];
+    for (int i = tid; i < P.bm_words; i += Q_THREADS) bm[i] = 0u;
+    if (tid == 0) s_ncand = 0;
+    __syncthreads();
+
+    uint64_t *pq = P.pq + qi * P.n_nodes;
+    int32_t *cand = P.cand + qi * P.cap;
+    uint64_t *keys = P.keys + qi * P.cap;
+    const bool roots_split = P.n_items > P.K;   // every root is a split node (count = N > K)
+
+    // ---- phase 1: the roots all sit at +inf and are expanded before anything else;
+    //      their margins are independent, so every wave takes a share.
+    if (w == 0) {
+        float pp = wave_dot(qv, qv, nvec, lane);
+        if (lane == 0) s_pp = pp;
+    }
+    if (roots_split) {
+        for (int t = w; t < T; t += Q_WAVES) {
+            const float m = wave_dot((const float4 *)(P.hp + (int64_t)P.node_hp[t] * P.dpad), qv, nvec, lane);
+            // slot s is only ever touched by lane s % 64 of wave 0 later on; written here once
+            if (lane == 0) {
+                pq[2 * t] = pq_key(m, P.node_rec[4 * t + 1]);       // min(+inf, margin), children[1]
+                pq[2 * t + 1] = pq_key(-m, P.node_rec[4 * t + 0]);  // min(+inf, -margin), children[0]
+            }
+        }
+    } else {
+        for (int t = tid; t < T; t += Q_THREADS) pq[t] = pq_key(INFINITY, t);
+    }
+    __syncthreads();
+
+    // ---- phase 2: best-first traversal by wave 0 (max-heap semantics on (bound, node id));
+    //      the queue is an unsorted array scanned by the wave, popped slots are zeroed.
+    int ndots = roots_split ? T : 0;
+    if (w == 0) {
+        int hn = roots_split ? 2 * T : T;
+        int64_t nn = 0;
+        const int64_t search_k = P.search_k;
+        while (nn < search_k) {
+            uint64_t best = 0;
+            int bestpos = -1;
+            for (int i = lane; i < hn; i += WAVE) {
+                uint64_t kk = pq[i];
+                if (kk > best) { best = kk; bestpos = i; }
+            }
+            const uint64_t top = wave_max_u64(best);
+            if (top == 0) break;                       // queue empty
+            if (best == top && bestpos >= 0) pq[bestpos] = 0;   // exactly one lane owns it
+            const int32_t node = (int32_t)(uint32_t)top;
+            const float d = f32_from_orderable((uint32_t)(top >> 32));
+            const int32_t c0 = P.node_rec[4 * node + 0], c1 = P.node_rec[4 * node + 1];
+            const int32_t start = P.node_rec[4 * node + 2], count = P.node_rec[4 * node + 3];
+            if (c0 < 0) {
+                // leaf: nns.insert(all ids); duplicates across trees are dropped by the bitmap
+                const int32_t *src_ids = P.perm + (int64_t)P.node_tree[node] * P.n_items + start;
+                for (int i = lane; i < count; i += WAVE) {
+                    const int32_t id = src_ids[i];
+                    const uint32_t bit = 1u << (id & 31);
+                    const uint32_t old = atomicOr(&bm[id >> 5], bit);
+                    if (!(old & bit)) {
+                        const int slot = atomicAdd(&s_ncand, 1);
+                        if (slot < P.cap) cand[slot] = id;
+                    }
+                }
+                nn += count;
+            } else {
+                const float m = wave_dot((const float4 *)(P.hp + (int64_t)P.node_hp[node] * P.dpad), qv, nvec, lane);
+                if (lane == (hn & (WAVE - 1))) pq[hn] = pq_key(d < m ? d : m, c1);
+                if (lane == ((hn + 1) & (WAVE - 1))) pq[hn + 1] = pq_key(d < -m ? d : -m, c0);
+                hn += 2;
+                ndots++;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: angular distance to every unique candidate row
+    const int ncand = s_ncand < P.cap ? s_ncand : P.cap;
+    const float pp = s_pp;
+    for (int c = w; c < ncand; c += Q_WAVES) {
+        const int32_t id = cand[c];
+        const float pqv = wave_dot((const float4 *)(P.X + (int64_t)id * P.dpad), qv, nvec, lane);
+        if (lane == 0) keys[c] = ((uint64_t)f32_orderable(ang_dist(pp, P.norm2[id], pqv)) << 32) | (uint32_t)id;
+    }
+    __syncthreads();
+
+    // ---- phase 4: k smallest (distance, id) pairs, in order
+    const int kout = P.k < ncand ? P.k : ncand;
+    uint64_t prev = 0;
+    bool have_prev = false;
+    for (int r = 0; r < kout; r++) {
+        uint64_t best = ~0ull;
+        for (int c = tid; c < ncand; c += Q_THREADS) {
+            const uint64_t kk = keys[c];
+            if ((!have_prev || kk > prev) && kk < best) best = kk;
+        }
+        best = block_min_u64(best, s_red, tid);
+        if (tid == 0) {
+            P.ids_out[qi * P.k + r] = (int32_t)(uint32_t)best;
+            const float d = f32_from_orderable((uint32_t)(best >> 32));
+            P.dist_out[qi * P.k + r] = sqrtf(d > 0.f ? d : 0.f);   // normalized_distance
+        }
+        prev = best;
+        have_prev = true;
+    }
+    for (int r = kout + tid; r < P.k; r += Q_THREADS) {
+        P.ids_out[qi * P.k + r] = -1;
+        P.dist_out[qi * P.k + r] = INFINITY;
+    }
+    if (tid == 0) {
+        P.count_out[qi] = kout;
+        atomicAdd(P.stat, (unsigned long long)(ndots + ncand + 1));
+    }
+}
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int query_batch(morna_index *h, const float *q_host, const int32_t *items_host, int64_t nq, int32_t k,
+                int32_t search_k, int32_t *ids_out, float *dist_out, int32_t *count_out)
+{
+    if (!h->built) {
+        set_error("index has not been built: call build() before searching");
+        return MORNA_E_STATE;
+    }
+    if (k <= 0 || nq < 0) {
+        set_error("get_nns: n must be positive");
+        return MORNA_E_INVALID;
+    }
+    if (nq == 0) return MORNA_OK;
+    if (search_k == -1) search_k = (int32_t)std::min<int64_t>((int64_t)k * h->n_trees, INT32_MAX);
+    if (items_host)
+        for (int64_t i = 0; i < nq; i++)
+            if (items_host[i] < 0 || items_host[i] >= h->n_items) {
+                set_error("item id %d out of range [0, %lld)", items_host[i], (long long)h->n_items);
+                return MORNA_E_RANGE;
+            }
+    const int64_t N = h->n_items;
+    // |nns| < search_k before the last pop, which adds at most K ids
+    const int64_t cap64 = std::min<int64_t>(N, (int64_t)std::max(search_k, 0) + h->K);
+    const int32_t cap = (int32_t)std::max<int64_t>(cap64, 1);
+    const int32_t bm_words = (int32_t)((N + 31) / 32);
+    const bool bm_lds = (size_t)bm_words * 4 <= 64 * 1024;
+    const size_t lds = (size_t)h->dpad * sizeof(float) + (bm_lds ? (size_t)bm_words * 4 : 0);
+
+    const size_t per_q = (size_t)h->n_nodes * 8 + (size_t)cap * 12 + (q_host ? (size_t)h->dpad * 4 : 0) +
+                         (bm_lds ? 0 : (size_t)bm_words * 4) + (size_t)k * 8 + 8;
+    const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(nq, (int64_t)(((size_t)1 << 30) / per_q)));
+    const size_t s_pq = align_up((size_t)batch * h->n_nodes * 8, 256), s_keys = align_up((size_t)batch * cap * 8, 256),
+                 s_q = q_host ? align_up((size_t)batch * h->dpad * 4, 256) : 0,
+                 s_cand = align_up((size_t)batch * cap * 4, 256),
+                 s_bm = bm_lds ? 0 : align_up((size_t)batch * bm_words * 4, 256),
+                 s_ids = align_up((size_t)batch * k * 4, 256), s_cnt = align_up((size_t)batch * 4, 256);
+    MORNA_TRY(h->ws.alloc(s_pq + s_keys + s_q + s_cand + s_bm + 2 * s_ids + s_cnt));
+    MORNA_TRY(h->d_stat.alloc(4));
+    DevBuf<int32_t> d_items;
+    if (items_host) MORNA_TRY(d_items.alloc((size_t)batch));
+
+    for (int64_t q0 = 0; q0 < nq; q0 += batch) {
+        const int64_t nb = std::min(batch, nq - q0);
+        uint8_t *p = h->ws.p;
+        QueryParams P;
+        P.X = h->X.p; P.norm2 = h->norm2.p; P.n_items = N; P.dpad = h->dpad; P.n_trees = h->n_trees; P.K = h->K;
+        P.node_rec = h->node_rec.p; P.node_tree = h->node_tree.p; P.node_hp = h->node_hp.p; P.hp = h->hp.p;
+        P.perm = h->perm.p; P.n_nodes = h->n_nodes;
+        P.k = k; P.search_k = search_k; P.cap = cap; P.bm_words = bm_words;
+        P.pq = (uint64_t *)p; p += s_pq;
+        P.keys = (uint64_t *)p; p += s_keys;
+        float *Qd = (float *)p; p += s_q;
+        P.cand = (int32_t *)p; p += s_cand;
+        P.bm_global = (uint32_t *)p; p += s_bm;
+        P.ids_out = (int32_t *)p; p += s_ids;
+        P.dist_out = (float *)p; p += s_ids;
+        P.count_out = (int32_t *)p; p += s_cnt;
+        P.stat = h->d_stat.p;
+        P.Q = nullptr; P.items = nullptr;
+        if (q_host) {
+            HIP_TRY(hipMemsetAsync(Qd, 0, (size_t)nb * h->dpad * 4, h->stream));
+            HIP_TRY(hipMemcpy2DAsync(Qd, (size_t)h->dpad * 4, q_host + q0 * h->dim, (size_t)h->dim * 4,
+                                     (size_t)h->dim * 4, (size_t)nb, hipMemcpyHostToDevice, h->stream));
+            P.Q = Qd;
+        } else {
+            HIP_TRY(hipMemcpyAsync(d_items.p, items_host + q0, (size_t)nb * 4, hipMemcpyHostToDevice, h->stream));
+            P.items = d_items.p;
+        }
+        {
+            // algorithmic bytes = 4*D*(hyperplane dots + unique candidates + 1) per
+            // query; the kernel counts them into d_stat[0], resolve_timers() prices them
+            ScopedTimer tm(h, MORNA_T_QUERY, 0);
+            if (bm_lds)
+                hipLaunchKernelGGL(query_kernel<true>, dim3((unsigned)nb), dim3(Q_THREADS), lds, h->stream, P);
+            else
+                hipLaunchKernelGGL(query_kernel<false>, dim3((unsigned)nb), dim3(Q_THREADS), lds, h->stream, P);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(ids_out + q0 * k, P.ids_out, (size_t)nb * k * 4, hipMemcpyDeviceToHost, h->stream));
+        if (dist_out)
+            HIP_TRY(hipMemcpyAsync(dist_out + q0 * k, P.dist_out, (size_t)nb * k * 4, hipMemcpyDeviceToHost, h->stream));
+        if (count_out)
+            HIP_TRY(hipMemcpyAsync(count_out + q0, P.count_out, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return MORNA_OK;
+}
+
+// =============================================================== exact search
+
+#define E_ROWS 64       // rows per workgroup
+
+// approx[q][row] = 2 - 2 cos in fp32 arithmetic (selection only, never returned)
+template <int E_QT>   // queries sharing one pass over a block of rows
+__global__ __launch_bounds__(256) void exact_scan_kernel(const float *__restrict__ X, const float *__restrict__ norm2,
+                                                         int64_t n_items, int32_t dpad,
+                                                         const float *__restrict__ Qf /* [nq][dpad] */,
+                                                         const float *__restrict__ qn2 /* [nq] */, int64_t nq,
+                                                         float *__restrict__ approx /* [nq][n_items] */)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *qs = (float4 *)smem;   // [E_QT][nvec]
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int nvec = dpad / 4;
+    const int64_t q0 = (int64_t)blockIdx.y * E_QT;
+    const int nqt = (int)((nq - q0) < E_QT ? (nq - q0) : E_QT);
+    for (int i = tid; i < E_QT * nvec; i += 256) {
+        int qq = i / nvec, v = i - qq * nvec;
+        qs[i] = qq < nqt ? ((const float4 *)(Qf + (q0 + qq) * dpad))[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * E_ROWS;
+    for (int rr = w; rr < E_ROWS; rr += 4) {
+        const int64_t r = r0 + rr;
+        if (r >= n_items) break;
+        const float4 *x = (const float4 *)(X + r * dpad);
+        float acc[E_QT];
+#pragma unroll
+        for (int qq = 0; qq < E_QT; qq++) acc[qq] = 0.f;
+        for (int i = lane; i < nvec; i += WAVE) {
+            const float4 xv = x[i];
+#pragma unroll
+            for (int qq = 0; qq < E_QT; qq++) {
+                const float4 qv = qs[qq * nvec + i];
+                acc[qq] += xv.x * qv.x + xv.y * qv.y + xv.z * qv.z + xv.w * qv.w;
+            }
+        }
+        const float rn = norm2[r];
+#pragma unroll
+        for (int qq = 0; qq < E_QT; qq++) {
+            const float pq = wave_sum_xor(acc[qq]);
+            if (lane == 0 && qq < nqt) {
+                const double ppqq = (double)rn * (double)qn2[q0 + qq];
+                approx[(q0 + qq) * n_items + r] = ppqq > 0.0 ? (float)(2.0 - 2.0 * (double)pq / sqrt(ppqq)) : 2.0f;
+            }
+        }
+    }
+}
+
+// per query: threshold = k-th smallest approx value; candidates = everything within eps of it
+__global__ __launch_bounds__(256) void exact_select_kernel(const float *__restrict__ approx, int64_t n_items,
+                                                           int32_t k, float eps, int32_t cap,
+                                                           int32_t *__restrict__ cand /* [nq][cap] */,
+                                                           int32_t *__restrict__ ncand_out /* [nq] */)
+{
+    __shared__ uint64_t s_red[Q_WAVES];
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    const int64_t qi = blockIdx.x;
+    const float *a = approx + qi * n_items;
+    const int kk = (int)(k < n_items ? k : n_items);
+    uint64_t prev = 0;
+    bool have_prev = false;
+    for (int r = 0; r < kk; r++) {
+        uint64_t best = ~0ull;
+        for (int64_t i = tid; i < n_items; i += 256) {
+            const uint64_t key = ((uint64_t)f32_orderable(a[i]) << 32) | (uint32_t)i;
+            if ((!have_prev || key > prev) && key < best) best = key;
+        }
+        best = block_min_u64(best, s_red, tid);
+        prev = best;
+        have_prev = true;
+    }
+    const float thr = f32_from_orderable((uint32_t)(prev >> 32)) + eps;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    for (int64_t i = tid; i < n_items; i += 256) {
+        if (a[i] <= thr) {
+            int slot = atomicAdd(&s_n, 1);
+            if (slot < cap) cand[qi * cap + slot] = (int32_t)i;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) ncand_out[qi] = s_n;   // may exceed cap: the host then retries with more room
+}
+
+// cosine_distance in the reference's order (morna.py:101-114): one thread per candidate
+__global__ __launch_bounds__(256) void exact_rerank_kernel(const float *__restrict__ X, int32_t dim, int32_t dpad,
+                                                           const double *__restrict__ Qd /* [nq][dim] */,
+                                                           const int32_t *__restrict__ cand, const int32_t *__restrict__ ncand,
+                                                           int32_t cap, int32_t k, double *__restrict__ cdist /* [nq][cap] */,
+                                                           int32_t *__restrict__ ids_out, double *__restrict__ dist_out,
+                                                           int32_t *__restrict__ count_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *qs = (double *)smem;   // [dim]
+    const int tid = threadIdx.x;
+    const int64_t qi = blockIdx.x;
+    for (int i = tid; i < dim; i += 256) qs[i] = Qd[qi * dim + i];
+    __syncthreads();
+    const int n = ncand[qi] < cap ? ncand[qi] : cap;
+    const int32_t *c = cand + qi * cap;
+    double *cd = cdist + qi * cap;
+    for (int t = tid; t < n; t += 256) {
+        const float *row = X + (int64_t)c[t] * dpad;
+        double pp = 0.0, qq = 0.0, pq = 0.0;
+        for (int z = 0; z < dim; z++) {
+            const double i = (double)row[z], j = qs[z];
+            pp = __dadd_rn(pp, __dmul_rn(i, i));
+            qq = __dadd_rn(qq, __dmul_rn(j, j));
+            pq = __dadd_rn(pq, __dmul_rn(i, j));
+        }
+        const double ppqq = __dmul_rn(pp, qq);
+        double distance = 2.0;
+        if (ppqq > 0.0) distance = __dsub_rn(2.0, __ddiv_rn(__dmul_rn(2.0, pq), __dsqrt_rn(ppqq)));
+        cd[t] = __dsqrt_rn(distance);   // NaN where Python's math.sqrt raises
+    }
+    __syncthreads();
+    // rank = number of candidates that bisect_left insertion leaves in front:
+    // smaller distance, or equal distance and HIGHER id (inserted later, lands first).
+    // NaN distances (Python would have raised) go last, by ascending id.
+    for (int t = tid; t < n; t += 256) {
+        const double d = cd[t];
+        const int32_t id = c[t];
+        const bool dnan = d != d;
+        int rank = 0;
+        for (int u = 0; u < n; u++) {
+            const double du = cd[u];
+            const bool unan = du != du;
+            bool before;
+            if (dnan) before = !unan || c[u] < id;
+            else before = (du < d) || (du == d && c[u] > id);
+            rank += (before && u != t) ? 1 : 0;
+        }
+        if (rank < k) {
+            ids_out[qi * k + rank] = id;
+            dist_out[qi * k + rank] = d;
+        }
+    }
+    const int kout = k < n ? k : n;
+    for (int r = kout + tid; r < k; r += 256) {
+        ids_out[qi * k + r] = -1;
+        dist_out[qi * k + r] = INFINITY;
+    }
+    if (tid == 0) count_out[qi] = kout;
+}
+
+// fp64 query -> fp32 image + its squared norm (selection pass only)
+__global__ void exact_prep_kernel(const double *__restrict__ Qd, int64_t nq, int32_t dim, int32_t dpad,
+                                  float *__restrict__ Qf, float *__restrict__ qn2)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    if (q >= nq) return;
+    float s = 0.f;
+    for (int i = lane; i < dpad; i += WAVE) {
+        float v = i < dim ? (float)Qd[q * dim + i] : 0.f;
+        Qf[q * dpad + i] = v;
+        s += v * v;
+    }
+    s = wave_sum_xor(s);
+    if (lane == 0) qn2[q] = s;
+}
+
+template <int QT>
+static void launch_exact_scan(morna_index *h, int64_t N, int64_t nb, const float *Qf, const float *qn2, float *approx)
+{
+    dim3 grid((unsigned)((N + E_ROWS - 1) / E_ROWS), (unsigned)((nb + QT - 1) / QT));
+    hipLaunchKernelGGL(exact_scan_kernel<QT>, grid, dim3(256), (size_t)QT * h->dpad * 4, h->stream, h->X.p,
+                       h->norm2.p, N, h->dpad, Qf, qn2, nb, approx);
+}
+
+int exact_search(morna_index *h, const double *q, int64_t nq, int32_t k, int32_t *ids_out, double *dist_out,
+                 int32_t *count_out)
+{
+    MORNA_TRY(upload_host_rows(h));
+    if (h->n_items <= 0) {
+        set_error("exact search on an empty index");
+        return MORNA_E_EMPTY;
+    }
+    if (k <= 0 || nq < 0) {
+        set_error("exact search: k must be positive");
+        return MORNA_E_INVALID;
+    }
+    if (nq == 0) return MORNA_OK;
+    const int64_t N = h->n_items;
+    const int32_t D = h->dim, dpad = h->dpad;
+    const float eps = 1e-4f;   // >> fp32 scan error (DESIGN.md "Exact search"); more candidates, never fewer
+    // queries resident per pass: their fp32 images share 64 KiB of LDS
+    const int qt = (size_t)dpad * 4 * 8 <= 65536 ? 8 : (size_t)dpad * 4 * 4 <= 65536 ? 4
+                   : (size_t)dpad * 4 * 2 <= 65536 ? 2 : 1;
+    if ((size_t)dpad * 4 > 160 * 1024 || (size_t)D * 8 > 160 * 1024) {
+        set_error("exact search: dimension %d does not fit LDS", D);
+        return MORNA_E_INVALID;
+    }
+    // queries per batch: approx[nq][N] floats capped at 2 GiB
+    const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)1 << 29) / std::max<int64_t>(N, 1)));
+    DevBuf<double> Qd, cdist, d_dist;
+    DevBuf<float> Qf, qn2, approx;
+    DevBuf<int32_t> cand, ncand, d_ids, d_cnt;
+    std::vector<int32_t> h_ncand((size_t)batch);
+    int32_t cap = std::max(64, 4 * k);
+    MORNA_TRY(Qd.alloc((size_t)batch * D));
+    MORNA_TRY(Qf.alloc((size_t)batch * dpad));
+    MORNA_TRY(qn2.alloc((size_t)batch));
+    MORNA_TRY(approx.alloc((size_t)batch * N));
+    MORNA_TRY(ncand.alloc((size_t)batch));
+    MORNA_TRY(d_ids.alloc((size_t)batch * k));
+    MORNA_TRY(d_dist.alloc((size_t)batch * k));
+    MORNA_TRY(d_cnt.alloc((size_t)batch));
+    for (int64_t q0 = 0; q0 < nq; q0 += batch) {
+        const int64_t nb = std::min(batch, nq - q0);
+        HIP_TRY(hipMemcpyAsync(Qd.p, q + q0 * D, (size_t)nb * D * 8, hipMemcpyHostToDevice, h->stream));
+        {
+            // one pass over the matrix per qt queries: 4*D*N bytes each
+            ScopedTimer tm(h, MORNA_T_EXACT, 4 * (int64_t)D * N * ((nb + qt - 1) / qt));
+            hipLaunchKernelGGL(exact_prep_kernel, dim3((unsigned)((nb * WAVE + 255) / 256)), dim3(256), 0, h->stream,
+                               Qd.p, nb, D, dpad, Qf.p, qn2.p);
+            if (qt == 8) launch_exact_scan<8>(h, N, nb, Qf.p, qn2.p, approx.p);
+            else if (qt == 4) launch_exact_scan<4>(h, N, nb, Qf.p, qn2.p, approx.p);
+            else if (qt == 2) launch_exact_scan<2>(h, N, nb, Qf.p, qn2.p, approx.p);
+            else launch_exact_scan<1>(h, N, nb, Qf.p, qn2.p, approx.p);
+        }
+        HIP_TRY(hipGetLastError());
+        for (;;) {
+            MORNA_TRY(cand.alloc((size_t)batch * cap));
+            MORNA_TRY(cdist.alloc((size_t)batch * cap));
+            hipLaunchKernelGGL(exact_select_kernel, dim3((unsigned)nb), dim3(256), 0, h->stream, approx.p, N, k, eps,
+                               cap, cand.p, ncand.p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(h_ncand.data(), ncand.p, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            int32_t need = 0;
+            for (int64_t i = 0; i < nb; i++) need = std::max(need, h_ncand[(size_t)i]);
+            if (need <= cap) break;
+            cap = need;   // huge tie groups at the boundary: make room for all of them
+        }
+        hipLaunchKernelGGL(exact_rerank_kernel, dim3((unsigned)nb), dim3(256), (size_t)D * 8, h->stream, h->X.p, D, dpad,
+                           Qd.p, cand.p, ncand.p, cap, k, cdist.p, d_ids.p, d_dist.p, d_cnt.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(ids_out + q0 * k, d_ids.p, (size_t)nb * k * 4, hipMemcpyDeviceToHost, h->stream));
+        if (dist_out) HIP_TRY(hipMemcpyAsync(dist_out + q0 * k, d_dist.p, (size_t)nb * k * 8, hipMemcpyDeviceToHost, h->stream));
+        if (count_out) HIP_TRY(hipMemcpyAsync(count_out + q0, d_cnt.p, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return MORNA_OK;
+}
+
+}  // namespace morna

@@ -1,0 +1,339 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle.  -m gpu
+
+Bars: bit-exact for hashes, the fp32 feature matrix, exact-search ids AND fp64
+distances, forest structure / hyperplanes / approximate results against oracle
+mode 1 (same algorithm, same seeds, same summation order); stated tolerances
+only where a test says so.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, angular64, assert_tie_aware_order
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from oracle import capi as c
+    c.lib()
+    return c
+
+
+@pytest.fixture(scope="module")
+def morna_ref():
+    from oracle import morna_ref as m
+    return m
+
+
+def _tokenized(morna_ref, lines):
+    keys, rp, s, c = [], [0], [], []
+    for ln in lines:
+        k, ss, cc = morna_ref.tokenize_line(ln)
+        keys.append(k)
+        s += ss
+        c += cc
+        rp.append(len(s))
+    return keys, np.array(rp, np.int64), np.array(s, np.int64), np.array(c, np.int64)
+
+
+def _gpu_features(keys, rp, s, c, sample_count, threshold, D):
+    from morna_amd.annoy import AnnoyIndex
+    from morna_amd.index import prepare_csr
+    prep = prepare_csr(keys, rp, s, c, sample_count, threshold)
+    a = AnnoyIndex(D)
+    a.stage_junctions(prep["key_bytes"], prep["key_off"], prep["row_ptr"], prep["ids"], prep["cov"], prep["idf"])
+    a.build_features(prep["n_items"])
+    return a, prep
+
+
+# --------------------------------------------------------------------- hashing
+
+def test_device_hash_golden():
+    from morna_amd.annoy import AnnoyIndex
+    from oracle.capi import pack_keys
+    with open(os.path.join(GOLDEN, "murmur3_vectors.json")) as fh:
+        g = json.load(fh)
+    keys = [k for k, _ in g["vectors"] if k]
+    buf, off = pack_keys(keys)
+    for D in (128, 3000):
+        a = AnnoyIndex(D)
+        h, col, sign = a.hash_keys(buf, off)
+        want = np.array([hv for k, hv in g["vectors"] if k], np.int64)
+        assert h.astype(np.int64).tolist() == want.tolist()
+        assert col.tolist() == [int(x) % D for x in want]            # Python floored modulo
+        assert sign.tolist() == [-1 if x < 0 else 1 for x in want]
+
+
+# -------------------------------------------------------------------- features
+
+@pytest.mark.parametrize("name", ["simple", "lossy", "lose_sample"])
+@pytest.mark.parametrize("D", [40, 128, 3000])
+def test_features_embedded_fixtures(embedded, embedded_mats, morna_ref, name, D):
+    spec = embedded["expected"][name]
+    keys, rp, s, c = _tokenized(morna_ref, embedded[spec["input"]])
+    a, prep = _gpu_features(keys, rp, s, c, spec["sample_count"], spec["sample_threshold"], D)
+    assert prep["n_items"] == spec["n_items"] == a.get_n_items()
+    X = a.get_items()
+    assert X.tobytes() == embedded_mats["%s_D%d_f32" % (name, D)].tobytes()
+    assert prep["ext_ids"].tolist() == embedded_mats["%s_D%d_ext_ids" % (name, D)].tolist()
+
+
+def test_features_tiny_intropolis(morna_ref):
+    g = np.load(os.path.join(GOLDEN, "tiny_intropolis_D128.npz"))
+    with open(os.path.join(GOLDEN, "tiny_intropolis.tsv")) as fh:
+        lines = fh.readlines()
+    keys, rp, s, c = _tokenized(morna_ref, lines)
+    a, prep = _gpu_features(keys, rp, s, c, 6850, 100, 128)
+    assert a.get_items().tobytes() == g["X"].tobytes()
+    assert prep["ext_ids"].tolist() == g["ext_ids"].tolist()
+
+
+def _synthetic_lines(rng, n_samples, J, lo, hi, dup_keys=True, weird=True):
+    keys, rp, s, c = [], [0], [], []
+    for j in range(J):
+        if dup_keys and j > 10 and rng.random() < 0.05:
+            keys.append(keys[int(rng.integers(0, j))])              # duplicate key: cumulative freq
+        else:
+            keys.append("chr%d %d %d" % (rng.integers(1, 23), rng.integers(10**4, 2 * 10**8), rng.integers(10**4, 2 * 10**8)))
+        n = int(rng.integers(lo, hi))
+        ids = np.sort(rng.choice(n_samples, size=min(n, n_samples), replace=False)) + 1
+        if weird:
+            r = rng.random()
+            if r < 0.1:
+                ids = ids[::-1]                                     # descending, as the lossy fixture
+            elif r < 0.2:
+                ids = rng.permutation(ids)                          # unordered -> serial path
+            elif r < 0.25 and len(ids) > 4:
+                ids = np.concatenate([ids, ids[:3]])                # a sample repeated inside a line
+        s += ids.tolist()
+        c += rng.integers(1, 200, size=len(ids)).tolist()
+        rp.append(len(s))
+    return keys, np.array(rp, np.int64), np.array(s, np.int64), np.array(c, np.int64)
+
+
+@pytest.mark.parametrize("D,n_samples,J", [(64, 700, 1500), (3000, 2000, 3000), (257, 300, 50)])
+def test_features_synthetic_vs_oracle(capi, D, n_samples, J):
+    rng = np.random.default_rng(8675309 + D)
+    keys, rp, s, c = _synthetic_lines(rng, n_samples, J, 5, 120)
+    buf, off = capi.pack_keys(keys)
+    ref = capi.index_features(buf, off, rp, s, c, n_samples, 20, D)
+    a, prep = _gpu_features(keys, rp, s, c, n_samples, 20, D)
+    assert prep["n_items"] == ref["n_items"]
+    assert prep["ext_ids"].tolist() == ref["ext_ids"].tolist()
+    assert prep["skipped"] == ref["skipped"]
+    assert a.get_items().tobytes() == ref["X"].tobytes()
+
+
+def test_row_norms_canonical(capi):
+    rng = np.random.default_rng(1)
+    for D in (40, 256, 3000):
+        X = rng.standard_normal((37, D)).astype(np.float32)
+        from morna_amd.annoy import AnnoyIndex
+        a = AnnoyIndex(D)
+        a.add_items(X)
+        n2 = a.get_norms2()
+        want = np.array([capi.dot(1, x, x) for x in X], np.float32)
+        assert n2.tobytes() == want.tobytes()
+
+
+def test_add_item_roundtrip_and_errors():
+    from morna_amd.annoy import AnnoyIndex
+    rng = np.random.default_rng(2)
+    a = AnnoyIndex(24)
+    V = rng.standard_normal((5, 24))
+    for i in range(5):
+        a.add_item(i, V[i].tolist())
+    assert a.get_n_items() == 5
+    for i in range(5):
+        assert a.get_item_vector(i) == [float(np.float32(x)) for x in V[i]]
+    with pytest.raises(IndexError):
+        a.get_item_vector(5)
+    with pytest.raises(RuntimeError):
+        a.get_nns_by_item(0, 3)          # not built
+    a.build(3)
+    with pytest.raises(RuntimeError):
+        a.add_item(5, V[0].tolist())     # annoy: can't add to a built index
+    with pytest.raises(IndexError):
+        a.get_nns_by_item(9, 3)
+    e = AnnoyIndex(8)
+    with pytest.raises(ValueError):
+        e.build(2)                       # no items
+
+
+# ---------------------------------------------------------------- exact search
+
+def test_exact_search_golden():
+    from morna_amd.annoy import AnnoyIndex
+    g = np.load(os.path.join(GOLDEN, "exact_search_512x128.npz"))
+    a = AnnoyIndex(128)
+    a.add_items(g["X"])
+    ids, d, cnt = a.exact_search_batch(g["Q"], 20)
+    assert cnt.tolist() == [20] * len(g["Q"])
+    assert ids.astype(np.int64).tolist() == g["ids"].tolist()
+    assert d.tobytes() == g["dists"].tobytes()
+
+
+@pytest.mark.parametrize("N,D,k", [(3000, 300, 20), (1500, 3000, 10), (40, 16, 64)])
+def test_exact_search_vs_oracle(capi, N, D, k):
+    from morna_amd.annoy import AnnoyIndex
+    rng = np.random.default_rng(N + D)
+    X = (rng.standard_normal((N, D)) * (rng.random((N, D)) < 0.2)).astype(np.float32)
+    X[N // 2] = X[3]
+    X[N // 2 + 1] = 3.0 * X[3]
+    Q = rng.standard_normal((9, D))
+    Q[0] = X[3]
+    Q[1] = X[5] * 0.5
+    a = AnnoyIndex(D)
+    a.add_items(X)
+    ids, d, cnt = a.exact_search_batch(Q, k)
+    for qi in range(len(Q)):
+        rid, rd = capi.exact_search(X, Q[qi], k)
+        m = int(cnt[qi])
+        assert m == len(rid)
+        assert ids[qi, :m].astype(np.int64).tolist() == rid.tolist()
+        assert d[qi, :m].tobytes() == rd.tobytes()
+
+
+# ------------------------------------------------------------ forest / approx
+
+@pytest.mark.parametrize("name", ["simple", "lossy", "lose_sample"])
+@pytest.mark.parametrize("D", [128, 3000])
+def test_embedded_orderings_gpu(embedded, embedded_mats, name, D):
+    """The reference's own known answers (morna.py:1176-1187, 1267-1278, 1312-1323):
+    20 trees, get_nns_by_item(i, 10, search_k=100)."""
+    from morna_amd.annoy import AnnoyIndex
+    spec = embedded["expected"][name]
+    X = embedded_mats["%s_D%d_f32" % (name, D)]
+    a = AnnoyIndex(D)
+    for i in range(X.shape[0]):
+        a.add_item(i, [float(x) for x in embedded_mats["%s_D%d_f64" % (name, D)][i]])
+    a.build(20)
+    assert a.get_n_items() == spec["n_items"]
+    for i, exp in enumerate(spec["orderings"]):
+        got = a.get_nns_by_item(i, 10, 100, include_distances=False)
+        assert_tie_aware_order(got, exp, angular64(X, i), tol=2e-6)
+
+
+def _clustered(rng, N, f, nc=12, noise=0.3):
+    centers = rng.standard_normal((nc, f))
+    return (centers[rng.integers(0, nc, N)] + noise * rng.standard_normal((N, f))).astype(np.float32)
+
+
+def _compare_forest(a, o, N, T):
+    """GPU forest vs oracle mode 1, node for node."""
+    f = a.get_forest()
+    rec = f["node_rec"]
+    assert o.n_nodes() == rec.shape[0]
+    hp_of = {int(n): i for i, n in enumerate(f["hp_node"])}
+    for nid in range(rec.shape[0]):
+        nd = o.node(nid)
+        kind, tree, start, count, c0, c1 = [int(x) for x in rec[nid]]
+        assert kind == nd["kind"], nid
+        assert tree == nd["tree"], nid
+        assert count == nd["n_desc"], nid
+        if kind == 1:
+            assert f["perm"][tree, start:start + count].tolist() == nd["items"].tolist(), nid
+        else:
+            assert (c0, c1) == (nd["child0"], nd["child1"]), nid
+            assert f["hyperplanes"][hp_of[nid]].tobytes() == nd["v"].tobytes(), nid
+
+
+@pytest.mark.parametrize("f,N,T", [(16, 3000, 8), (40, 5000, 5), (300, 4000, 3)])
+def test_forest_bit_exact_vs_oracle_wave_order(capi, f, N, T):
+    from morna_amd.annoy import AnnoyIndex
+    rng = np.random.default_rng(8675309 + f)
+    X = _clustered(rng, N, f)
+    X[17] = 0.0                       # a zero row: norm == 0 paths, margin == 0 coin flips
+    X[18] = X[19]
+    o = capi.AnnoyOracle(f, mode=1)
+    o.set_items(X)
+    o.build(T)
+    a = AnnoyIndex(f)
+    a.add_items(X)
+    a.build(T)
+    st = a.forest_stats()
+    assert st["split_rows"] == o.split_rows() and st["split_attempts"] == o.split_nodes()
+    _compare_forest(a, o, N, T)
+    # approximate search: same candidates, same order, same fp32 distances
+    items = np.arange(0, 120, dtype=np.int32)
+    for n, sk in ((10, -1), (20, 100), (5, 1), (50, 3000)):
+        ids, d, cnt = a.get_nns_by_item_batch(items, n, sk)
+        for qi, it in enumerate(items):
+            (rid, rd) = o.get_nns_by_item(int(it), n, sk, include_distances=True)
+            m = int(cnt[qi])
+            assert ids[qi, :m].tolist() == rid, (it, n, sk)
+            assert d[qi, :m].tobytes() == np.array(rd, np.float32).tobytes(), (it, n, sk)
+    Q = rng.standard_normal((16, f)).astype(np.float32)
+    ids, d, cnt = a.get_nns_by_vector_batch(Q, 10, -1)
+    for qi in range(len(Q)):
+        rid, rd = o.get_nns_by_vector(Q[qi], 10, -1, include_distances=True)
+        assert ids[qi, :int(cnt[qi])].tolist() == rid
+        assert d[qi, :int(cnt[qi])].tobytes() == np.array(rd, np.float32).tobytes()
+
+
+def test_forest_degenerate_inputs(capi):
+    """All rows identical (every split is 100% imbalanced -> random fallback) and
+    a matrix of zeros (every margin is exactly 0 -> coin flips)."""
+    from morna_amd.annoy import AnnoyIndex
+    f, N, T = 8, 700, 3
+    for X in (np.ones((N, f), np.float32), np.zeros((N, f), np.float32)):
+        o = capi.AnnoyOracle(f, mode=1)
+        o.set_items(X)
+        o.build(T)
+        a = AnnoyIndex(f)
+        a.add_items(X)
+        a.build(T)
+        _compare_forest(a, o, N, T)
+        assert a.forest_stats()["n_leaves"] > T
+        got = a.get_nns_by_item(5, 10, -1)
+        assert got == o.get_nns_by_item(5, 10, -1)
+
+
+def test_recall_matches_faithful_annoy_restatement(capi):
+    """Approximate search quality against the faithful (sequential Kiss32,
+    depth-first) restatement: recall@10 of the GPU forest must be within 0.05
+    of it at the same n_trees / search_k; every returned distance must be the
+    true angular distance within 1e-5."""
+    from morna_amd.annoy import AnnoyIndex
+    rng = np.random.default_rng(11)
+    f, N, T, k = 32, 6000, 10, 10
+    X = _clustered(rng, N, f, nc=40, noise=0.6)
+    o = capi.AnnoyOracle(f, mode=0)
+    o.set_items(X)
+    o.build(T)
+    a = AnnoyIndex(f)
+    a.add_items(X)
+    a.build(T)
+    items = np.arange(300, dtype=np.int32)
+    ids, d, cnt = a.get_nns_by_item_batch(items, k, -1)
+    hit_g = hit_o = 0
+    for qi, it in enumerate(items):
+        dd = angular64(X, int(it))
+        true = set(np.argsort(dd, kind="stable")[:k].tolist())
+        hit_g += len(true & set(ids[qi, :int(cnt[qi])].tolist()))
+        hit_o += len(true & set(o.get_nns_by_item(int(it), k, -1)))
+        want = np.sqrt(np.maximum(dd[ids[qi, :int(cnt[qi])]], 0))
+        assert np.allclose(d[qi, :int(cnt[qi])], want, atol=1e-5)
+    assert hit_g / (k * len(items)) >= hit_o / (k * len(items)) - 0.05
+
+
+def test_save_load_roundtrip(tmp_path):
+    from morna_amd.annoy import AnnoyIndex
+    rng = np.random.default_rng(4)
+    X = _clustered(rng, 2500, 24)
+    a = AnnoyIndex(24)
+    a.add_items(X)
+    a.build(6)
+    want = a.get_nns_by_item_batch(np.arange(50, dtype=np.int32), 10, -1)
+    a.save(str(tmp_path / "t.annoy.mor"))
+    b = AnnoyIndex(24)
+    b.load(str(tmp_path / "t.annoy.mor"))
+    assert b.get_n_items() == 2500 and b.get_n_trees() == 6
+    got = b.get_nns_by_item_batch(np.arange(50, dtype=np.int32), 10, -1)
+    assert got[0].tolist() == want[0].tolist() and got[1].tobytes() == want[1].tobytes()
+    with pytest.raises(IOError):
+        AnnoyIndex(25).load(str(tmp_path / "t.annoy.mor"))
