@@ -124,6 +124,7 @@ __device__ inline float ang_dist(float pp, float qq, float pq)
 // order-preserving map float -> uint32 (total order of non-NaN values)
 __device__ inline uint32_t f32_orderable(float f)
 {
+    if (f == 0.f) f = 0.f;   // -0.0 and +0.0 compare equal on the CPU: one key for both
     uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }

@@ -183,7 +183,7 @@ def test_exact_search_vs_oracle(capi, N, D, k):
     rng = np.random.default_rng(N + D)
     X = (rng.standard_normal((N, D)) * (rng.random((N, D)) < 0.2)).astype(np.float32)
     X[N // 2] = X[3]
-    X[N // 2 + 1] = 3.0 * X[3]
+    X[N // 2 + 1] = 2.0 * X[3]        # exact scaling: cos is exactly 1, no negative radicand
     Q = rng.standard_normal((9, D))
     Q[0] = X[3]
     Q[1] = X[5] * 0.5
