@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Headline benchmark: morna index-build + 1000-query k-NN on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic intropolis
+already resident in HBM: feature-hashed TF-IDF matrix build (hash, accumulate,
+fp32 convert, row norms) + 200-tree forest build + 1000 by-item queries (k=20,
+morna's default search_k=100).  Default workload = BASELINE.json configs[2]:
+50k samples x 3000 features on one GPU.  With --gpus N every rank holds its own
+50k-sample shard (weak scaling); queries are answered by every shard and merged
+by an RCCL all-gather of the per-shard top-k (no other collective on the path).
+
+Prints ONE JSON line (rank 0).  `value` = samples indexed per second over the
+whole step (build + queries), all ranks.  `roofline` is for the dominant kernel,
+the forest split kernel (hyperplane dot + side of every row of every split
+node): algorithmic bytes 4*D*(sum|node| + #nodes) per launch over
+its HIP-event time on the library's own stream.  `cpu_baseline` times the CPU
+oracle (faithful single-thread restatement of morna + annoy) on a bounded sample
+of the same workload and extrapolates to the full step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--samples", type=int, default=50_000, help="samples per GPU")
+    ap.add_argument("--features", type=int, default=3000)
+    ap.add_argument("--trees", type=int, default=200)
+    ap.add_argument("--queries", type=int, default=1000)
+    ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--search-k", type=int, default=100)
+    ap.add_argument("--junctions", type=int, default=70_000,
+                    help="junction lines; 70k gives nnz ~ 2000 per sample (SURVEY.md 8d)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-trees", type=int, default=2)
+    ap.add_argument("--cpu-queries", type=int, default=50)
+    ap.add_argument("--verify", action="store_true", help="check results against the exact search")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, data, prep, items):
+    """Oracle (port of morna.py + annoy, 1 thread) on a bounded sample, extrapolated."""
+    from oracle import capi
+    N, D = prep["n_items"], args.features
+    # (1) feature accumulation on a prefix of the junction lines (~1/8 of nnz)
+    J = len(data["keys"])
+    Js = max(1, J // 8)
+    nnz_s = int(data["row_ptr"][Js])
+    buf, off = capi.pack_keys(data["keys"][:Js])
+    t0 = time.perf_counter()
+    ref = capi.index_features(buf, off, data["row_ptr"][:Js + 1], data["samples"][:nnz_s], data["cov"][:nnz_s],
+                              data["sample_count"], 100, D, max_items=N)
+    t_feat = (time.perf_counter() - t0) * (len(data["samples"]) / max(nnz_s, 1))
+    del ref
+    # (2) forest: cpu_trees of the 200 trees on the full matrix
+    X = prep["X_host"]
+    o = capi.AnnoyOracle(D, mode=0)
+    o.set_items(X)
+    t0 = time.perf_counter()
+    o.build(args.cpu_trees)
+    t_tree = (time.perf_counter() - t0) / args.cpu_trees
+    # (3) queries against that forest; per-query cost grows with n_trees (one
+    # hyperplane dot per root), candidates = one leaf either way at search_k=100
+    nq = min(args.cpu_queries, len(items))
+    t0 = time.perf_counter()
+    for it in items[:nq]:
+        o.get_nns_by_item(int(it), args.k, args.search_k)
+    t_q_small = (time.perf_counter() - t0) / nq
+    # price the missing root dots: (trees - cpu_trees) extra dots of length D per query
+    xs = X[:64]
+    t0 = time.perf_counter()
+    for _ in range(4):
+        for r in xs:
+            capi.dot(0, r, xs[0])
+    t_dot = (time.perf_counter() - t0) / (4 * len(xs))
+    t_q = t_q_small + (args.trees - args.cpu_trees) * t_dot
+    total = t_feat + t_tree * args.trees + t_q * args.queries
+    return dict(value=N / total, unit="samples/s", cores=1, kind="port",
+                sample=("oracle/ (C restatement of morna.py add_junction + annoy, 1 thread): features on the first "
+                        "%d of %d junction lines, %d of %d trees on the full %dx%d matrix, %d of %d queries; "
+                        "extrapolated: features %.1fs + forest %.1fs + queries %.1fs"
+                        % (Js, J, args.cpu_trees, args.trees, N, D, nq, args.queries, t_feat, t_tree * args.trees,
+                           t_q * args.queries)))
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from morna_amd import build as hip_build
+    if rank == 0:
+        hip_build.build()
+    if world > 1:
+        dist.barrier()
+    from morna_amd.annoy import AnnoyIndex
+    from morna_amd.index import prepare_csr
+    from morna_amd.synth import SEED, query_items, synthetic_intropolis
+    from morna_amd.dist import ShardedSearch
+
+    N, D, T, Q, k = args.samples, args.features, args.trees, args.queries, args.k
+    data = synthetic_intropolis(N, J=args.junctions, seed=SEED + rank)
+    prep = prepare_csr(data["keys"], data["row_ptr"], data["samples"], data["cov"], data["sample_count"], 100)
+    n_items = prep["n_items"]
+    index = AnnoyIndex(D, device=local_rank)
+    index.stage_junctions(prep["key_bytes"], prep["key_off"], prep["row_ptr"], prep["ids"], prep["cov"], prep["idf"])
+    items = query_items(n_items, Q)              # the queries this rank owns (all of them when world == 1)
+    sharded = ShardedSearch(index, rank, world, n_items) if world > 1 else None
+    if sharded is not None:
+        items = items[rank::world]
+
+    def step():
+        t0 = time.perf_counter()
+        index.build_features(n_items)
+        index.build(T, seed=0)
+        index.synchronize()
+        t1 = time.perf_counter()
+        if sharded is None:
+            res = index.get_nns_by_item_batch(items, k, args.search_k)
+        else:
+            res = sharded.get_nns_by_local_items(items, k, args.search_k)
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1, res
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        index.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    index.timer_reset()
+    index.timer_enable(True)
+    fence()
+    t_start = time.perf_counter()
+    tb = tq = 0.0
+    res = None
+    for _ in range(args.steps):
+        b, q, res = step()
+        tb += b
+        tq += q
+    fence()
+    elapsed = time.perf_counter() - t_start
+    index.timer_enable(False)
+    timers = index.timers()
+    if world > 1:
+        t = torch.tensor([elapsed, tb, tq], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, tb, tq = [float(x) for x in t.tolist()]
+    st = index.forest_stats()
+
+    out = None
+    if rank == 0:
+        sp = timers["split"]
+        achieved = (sp["bytes"] / 1e9) / (sp["ms"] / 1e3) if sp["ms"] > 0 else 0.0
+        total_samples = n_items * world * args.steps
+        out = {
+            "metric": "samples indexed/sec (index build + %d queries, k=%d) at %dk x %d" % (Q, k, N // 1000, D),
+            "value": total_samples / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic intropolis %d samples/GPU x %d features, %d trees, %d by-item queries, "
+                                   "k=%d, search_k=%d (BASELINE.json configs[2])" % (N, D, T, Q, k, args.search_k),
+                       "samples_per_gpu": n_items, "features": D, "n_trees": T, "queries": Q, "k": k,
+                       "search_k": args.search_k, "nnz_per_gpu": int(len(prep["ids"])), "junction_lines": int(len(prep["idf"])),
+                       "parallelism": "rows sharded over %d GPU(s), RCCL all-gather of per-shard top-k" % world},
+            "index_samples_per_sec": n_items * world * args.steps / tb,
+            "queries_per_sec": Q * args.steps / tq,
+            "build_ms_per_step": 1e3 * tb / args.steps, "query_ms_per_step": 1e3 * tq / args.steps,
+            "kernel_ms_per_step": {n: round(v["ms"] / args.steps, 3) for n, v in timers.items()},
+            "forest": {"n_nodes": st["n_nodes"], "n_split": st["n_split"], "max_depth": st["max_depth"],
+                       "split_rows": st["split_rows"], "split_attempts": st["split_attempts"],
+                       "fallback_nodes": st["fallback_nodes"]},
+            "roofline": {"kernel": "split_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "launches": sp["launches"] // max(args.steps, 1),
+                         "alg_bytes_per_step": sp["bytes"] // max(args.steps, 1),
+                         "traffic": None},
+        }
+        if args.verify:
+            ids = res[0]
+            eids, _, _ = index.exact_search_batch(index.get_items()[items[:64]].astype(np.float64), k)
+            rec = np.mean([len(set(ids[i].tolist()) & set(eids[i].tolist())) / float(k) for i in range(len(eids))])
+            out["recall_at_k_vs_exact"] = float(rec)
+        if world == 1 and not args.no_cpu_baseline:
+            prep["X_host"] = index.get_items()
+            out["cpu_baseline"] = cpu_baseline(args, data, prep, items)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

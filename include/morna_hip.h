@@ -78,6 +78,8 @@ int morna_hash_keys(morna_index *h, const uint8_t *key_bytes, const int64_t *key
 int64_t morna_get_n_items(const morna_index *h);
 /* AnnoyIndex.get_item_vector(i)                                morna.py:702 */
 int morna_get_item_vector(morna_index *h, int32_t id, float *out);
+/* rows of several items at once: out[n][dim] (query vectors of a row-sharded search) */
+int morna_get_item_vectors(morna_index *h, const int32_t *ids, int64_t n, float *out);
 /* whole matrix / squared norms, for tests */
 int morna_get_items(morna_index *h, float *rows_out /* [n][dim] */);
 int morna_get_norms2(morna_index *h, float *out /* [n] */);

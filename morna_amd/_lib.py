@@ -39,6 +39,7 @@ SIGNATURES = {
     "morna_hash_keys": (C.c_int, [_p, _p, _p, _i64, _p, _p, _p]),
     "morna_get_n_items": (_i64, [_p]),
     "morna_get_item_vector": (C.c_int, [_p, _i32, _p]),
+    "morna_get_item_vectors": (C.c_int, [_p, _p, _i64, _p]),
     "morna_get_items": (C.c_int, [_p, _p]),
     "morna_get_norms2": (C.c_int, [_p, _p]),
     "morna_build": (C.c_int, [_p, _i32, _u32]),

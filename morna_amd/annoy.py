@@ -58,6 +58,12 @@ class AnnoyIndex(object):
         check(lib().morna_get_item_vector(self._h, int(i), ptr(out)))
         return [float(x) for x in out]
 
+    def get_item_vectors(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        out = np.empty((len(ids), self.f), dtype=np.float32)
+        check(lib().morna_get_item_vectors(self._h, ptr(ids), len(ids), ptr(out)))
+        return out
+
     def get_items(self):
         out = np.empty((self.get_n_items(), self.f), dtype=np.float32)
         check(lib().morna_get_items(self._h, ptr(out)))

@@ -274,6 +274,23 @@ int morna_get_item_vector(morna_index *h, int32_t id, float *out)
     return MORNA_OK;
 }
 
+int morna_get_item_vectors(morna_index *h, const int32_t *ids, int64_t n, float *out)
+{
+    CHECK_H(h);
+    HIP_TRY(hipSetDevice(h->device));
+    MORNA_TRY(upload_host_rows(h));
+    for (int64_t i = 0; i < n; i++)
+        if (ids[i] < 0 || ids[i] >= h->n_items) {
+            set_error("Item index %d out of range [0, %lld)", ids[i], (long long)h->n_items);
+            return MORNA_E_RANGE;
+        }
+    for (int64_t i = 0; i < n; i++)
+        HIP_TRY(hipMemcpyAsync(out + i * h->dim, h->X.p + (size_t)ids[i] * h->dpad, (size_t)h->dim * 4,
+                               hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MORNA_OK;
+}
+
 int morna_get_items(morna_index *h, float *rows_out)
 {
     CHECK_H(h);

@@ -1,0 +1,100 @@
+"""Row-sharded search: the all-gather + merge path on 2 ranks (gloo, CPU).
+
+The local shard is a numpy stand-in with the AnnoyIndex-shaped interface
+ShardedSearch drives (exact angular top-k in fp32); what is under test is the
+distributed logic: offsets, the top-k all-gather, the (distance, id) merge.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from morna_amd.dist import ShardedSearch, merge_topk
+
+
+class NumpyShard(object):
+    def __init__(self, X):
+        self.X = np.asarray(X, np.float32)
+        self.f = self.X.shape[1]
+
+    def get_item_vectors(self, ids):
+        return self.X[np.asarray(ids, np.int64)]
+
+    def get_nns_by_vector_batch(self, Q, k, search_k=-1):
+        Q = np.asarray(Q, np.float32)
+        n2 = (self.X * self.X).sum(1)
+        ids = np.full((len(Q), k), -1, np.int32)
+        d = np.full((len(Q), k), np.inf, np.float32)
+        cnt = np.zeros(len(Q), np.int32)
+        for i, q in enumerate(Q):
+            ppqq = n2 * float(q @ q)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                dd = np.where(ppqq > 0, 2.0 - 2.0 * (self.X @ q) / np.sqrt(ppqq), 2.0).astype(np.float32)
+            order = np.lexsort((np.arange(len(dd)), dd))[:k]
+            m = len(order)
+            ids[i, :m] = order
+            d[i, :m] = np.sqrt(np.maximum(dd[order], 0))
+            cnt[i] = m
+        return ids, d, cnt
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(8675309)
+        X = rng.standard_normal((901, 24)).astype(np.float32)
+        X[700] = X[3]                                   # a cross-shard exact tie
+        bounds = [0, 400, 901]                          # ragged shards
+        shard = NumpyShard(X[bounds[rank]:bounds[rank + 1]])
+        ss = ShardedSearch(shard, rank, world, bounds[rank + 1] - bounds[rank])
+        assert ss.offsets.tolist() == bounds and ss.n_total == 901
+        Q = rng.standard_normal((7, 24)).astype(np.float32)
+        Q[0] = X[3]
+        ids, d, cnt = ss.get_nns_by_vector(Q, 10)
+        full = NumpyShard(X).get_nns_by_vector_batch(Q, 10)
+        assert ids.tolist() == full[0].astype(np.int64).tolist()
+        assert np.array_equal(d, full[1])
+        assert ids[0, :2].tolist() == [3, 700]          # equal distance: lower global id first
+        # by-item form: rank 0 asks about 3 of its rows, rank 1 about 2 of its rows
+        mine = np.array([1, 5, 9], np.int32) if rank == 0 else np.array([0, 17], np.int32)
+        ids2, d2, _ = ss.get_nns_by_local_items(mine, 5)
+        gl = [1, 5, 9, 400, 417]
+        full2 = NumpyShard(X).get_nns_by_vector_batch(X[gl], 5)
+        assert ids2.tolist() == full2[0].astype(np.int64).tolist()
+        # k larger than a shard: padded slots must not leak into the merge
+        tiny = ShardedSearch(NumpyShard(X[:3] if rank == 0 else X[3:5]), rank, world, 3 if rank == 0 else 2)
+        ids3, _, cnt3 = tiny.get_nns_by_vector(Q[:2], 8)
+        assert cnt3.tolist() == [5, 5] and (ids3[:, 5:] == -1).all()
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_search_two_ranks_gloo():
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def test_merge_topk_ties_and_padding():
+    ids = np.array([[[5, 9, -1]], [[2, 7, 11]]], np.int64)          # [world=2, nq=1, k=3]
+    d = np.array([[[0.1, 0.5, np.inf]], [[0.1, 0.2, 0.9]]], np.float32)
+    oi, od, cnt = merge_topk(ids, d, 4)
+    assert oi.tolist() == [[2, 5, 7, 9]] and cnt.tolist() == [4]
+    oi, od, cnt = merge_topk(ids, d, 6)
+    assert oi.tolist() == [[2, 5, 7, 9, 11, -1]] and cnt.tolist() == [5]
