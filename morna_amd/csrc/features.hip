@@ -5,16 +5,18 @@
 // matrix is BIT-IDENTICAL to the reference's, which sums fp64 contributions per
 // (sample, column) cell in file order and rounds once to fp32.
 //
-// Data flow (all in HBM, one pass over the nnz stream):
-//   hash_keys_kernel     J keys -> column, sign*idf
-//   line_flags_kernel    marks lines whose id list is not strictly monotone
-//                        (the only lines that could repeat a sample)
-//   accumulate_kernel    one workgroup per feature COLUMN: walks the junction
-//                        lines that hash to its column in file order and adds
-//                        cov*idf into an fp64 column image [N] that stays in L2;
-//                        distinct columns never share a cell, lines of one
-//                        column are serialised by the workgroup barrier, so the
-//                        per-cell order is the file order with no atomics.
+// Data flow (all in HBM; the nnz stream is read once, coalesced):
+//   hash_keys_kernel     J keys -> column, sign*idf; counts lines per column
+//   col_scan / col_fill  lines bucketed by column, file order kept inside a bucket
+//   line_flags_kernel    does a sample repeat inside a line? (LDS bitmap per line)
+//   accumulate_kernel    one workgroup per (column, tile of 8192 samples): the
+//                        tile's fp64 accumulators live in LDS; the lines of the
+//                        column are walked in file order, the lanes pick the
+//                        entries whose sample falls in the tile, one workgroup
+//                        barrier between lines.  Different (column, tile) pairs
+//                        never share a cell and a line touches a cell at most
+//                        once (else it is replayed serially), so the per-cell
+//                        order is the file order, with no atomics.
 //   transpose_convert    fp64 [D][N] -> fp32 [N][dpad] through an LDS tile
 //   row_norms_kernel     canonical dot(x, x) per row
 #include <algorithm>
@@ -30,7 +32,8 @@ namespace morna {
 __global__ void hash_keys_kernel(const uint8_t *__restrict__ keys, const int64_t *__restrict__ key_off,
                                  int64_t J, int32_t dim, const double *__restrict__ idf,
                                  int32_t *__restrict__ col_out, double *__restrict__ sidf_out,
-                                 int32_t *__restrict__ hash_out, int32_t *__restrict__ sign_out)
+                                 int32_t *__restrict__ hash_out, int32_t *__restrict__ sign_out,
+                                 int32_t *__restrict__ col_count)
 {
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= J) return;
@@ -41,48 +44,50 @@ __global__ void hash_keys_kernel(const uint8_t *__restrict__ keys, const int64_t
     if (sidf_out) sidf_out[j] = h < 0 ? -idf[j] : idf[j];   // multiplier * (cov * idf): sign is exact
     if (hash_out) hash_out[j] = h;
     if (sign_out) sign_out[j] = h < 0 ? -1 : 1;             // morna.py:370, before the modulo
+    if (col_count) atomicAdd(&col_count[col], 1);
 }
 
-// One wave per line: flag lines whose item ids are not strictly monotone.
-__global__ void line_flags_kernel(const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ ids,
-                                  int64_t J, uint8_t *__restrict__ serial_out)
+// exclusive scan of the per-column line counts (one workgroup)
+__global__ __launch_bounds__(1024) void col_scan_kernel(const int32_t *__restrict__ count, int32_t dim,
+                                                        int32_t *__restrict__ off /* [dim + 1] */)
 {
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) / WAVE;
-    for (int64_t j = wave; j < J; j += nwaves) {
-        int64_t b = row_ptr[j], e = row_ptr[j + 1];
-        int inc = 1, dec = 1;
-        for (int64_t t = b + lane; t + 1 < e; t += WAVE) {
-            int32_t a = ids[t], c = ids[t + 1];
-            inc &= (a < c);
-            dec &= (a > c);
-        }
-        inc = __all(inc);
-        dec = __all(dec);
-        if (lane == 0) serial_out[j] = (inc || dec) ? 0 : 1;
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (dim + 1023) / 1024;
+    const int lo = tid * per, hi = lo + per < dim ? lo + per : dim;
+    int sum = 0;
+    for (int i = lo; i < hi; i++) sum += count[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        int v = tid >= o ? s_part[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
     }
+    int run = tid ? s_part[tid - 1] : 0;
+    for (int i = lo; i < hi; i++) {
+        off[i] = run;
+        run += count[i];
+    }
+    if (tid == 1023) off[dim] = s_part[1023];
 }
-
-// ------------------------------------------------------------ accumulate pass
 
 #define ACC_THREADS 256
 
-__global__ __launch_bounds__(ACC_THREADS) void accumulate_kernel(
-    const int32_t *__restrict__ col, const double *__restrict__ sidf, const uint8_t *__restrict__ serial,
-    const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ ids, const int32_t *__restrict__ cov,
-    int64_t J, int64_t n_items, double *__restrict__ colacc /* [D][n_items] */)
+// one workgroup per column: ordered list of the lines that hash to it
+__global__ __launch_bounds__(ACC_THREADS) void col_fill_kernel(const int32_t *__restrict__ col, int64_t J,
+                                                               const int32_t *__restrict__ off,
+                                                               int32_t *__restrict__ lines)
 {
-    __shared__ int s_list[ACC_THREADS];
     __shared__ int s_wcnt[ACC_THREADS / WAVE];
     const int c = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
-    double *acc = colacc + (int64_t)c * n_items;
-
+    int32_t *dst = lines + off[c];
+    int run = 0;
     for (int64_t j0 = 0; j0 < J; j0 += ACC_THREADS) {
         const int64_t j = j0 + tid;
         const bool m = j < J && col[j] == c;
-        // ordered compaction of this chunk's matching lines
         const unsigned long long bal = __ballot(m);
         if (lane == 0) s_wcnt[w] = __popcll(bal);
         __syncthreads();
@@ -93,30 +98,97 @@ __global__ __launch_bounds__(ACC_THREADS) void accumulate_kernel(
             if (i < w) before += n;
             total += n;
         }
-        if (m) s_list[before + __popcll(bal & ((1ull << lane) - 1ull))] = tid;
+        if (m) dst[run + before + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)j;
+        run += total;
         __syncthreads();
-        for (int i = 0; i < total; i++) {
-            const int64_t jj = j0 + s_list[i];
-            const int64_t b = row_ptr[jj], e = row_ptr[jj + 1];
-            const double wgt = sidf[jj];
-            if (serial[jj]) {
-                // a sample may repeat inside this line: keep the line's own order
+    }
+}
+
+// One workgroup per line: does any sample id repeat inside the line?  (Internal
+// ids follow first-seen order, so a line's id list is generally NOT sorted even
+// though the file's sample list is.)  Uses an LDS bitmap over the samples.
+#define FLAG_MAX_WORDS 32768   // 128 KiB of LDS: up to 2^20 samples
+__global__ __launch_bounds__(256) void line_flags_kernel(const int64_t *__restrict__ row_ptr,
+                                                         const int32_t *__restrict__ ids, int64_t J,
+                                                         int32_t n_words, uint8_t *__restrict__ flag_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *bm = (uint32_t *)smem;
+    __shared__ int s_dup;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n_words; i += 256) bm[i] = 0u;
+    __syncthreads();
+    for (int64_t j = blockIdx.x; j < J; j += gridDim.x) {
+        const int64_t b = row_ptr[j], e = row_ptr[j + 1];
+        if (tid == 0) s_dup = 0;
+        __syncthreads();
+        int dup = 0;
+        for (int64_t t = b + tid; t < e; t += 256) {
+            const uint32_t id = (uint32_t)ids[t];
+            const uint32_t bit = 1u << (id & 31);
+            dup |= (atomicOr(&bm[id >> 5], bit) & bit) != 0;
+        }
+        if (dup) s_dup = 1;
+        __syncthreads();
+        if (tid == 0) flag_out[j] = (uint8_t)s_dup;
+        for (int64_t t = b + tid; t < e; t += 256) bm[(uint32_t)ids[t] >> 5] = 0u;   // un-set only what was set
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------ accumulate pass
+
+#define ACC_TILE 8192     // samples per tile: 64 KiB of fp64 accumulators in LDS
+#define ACC_LINES 256     // lines whose extents are staged per pass
+
+__global__ __launch_bounds__(ACC_THREADS) void accumulate_kernel(
+    const int32_t *__restrict__ col_off, const int32_t *__restrict__ col_lines, const double *__restrict__ sidf,
+    const uint8_t *__restrict__ flags, const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ ids,
+    const int32_t *__restrict__ cov, int64_t n_items, double *__restrict__ colacc /* [D][n_items] */)
+{
+    __shared__ double acc[ACC_TILE];
+    __shared__ int64_t s_b[ACC_LINES], s_e[ACC_LINES];
+    __shared__ double s_w[ACC_LINES];
+    __shared__ uint8_t s_f[ACC_LINES];
+    const int c = blockIdx.y;
+    const int64_t r_lo = (int64_t)blockIdx.x * ACC_TILE;
+    const int64_t r_hi = r_lo + ACC_TILE < n_items ? r_lo + ACC_TILE : n_items;
+    const uint32_t span = (uint32_t)(r_hi - r_lo);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < ACC_TILE; i += ACC_THREADS) acc[i] = 0.0;
+    const int nl = col_off[c + 1] - col_off[c];
+    const int32_t *lines = col_lines + col_off[c];
+
+    for (int l0 = 0; l0 < nl; l0 += ACC_LINES) {
+        const int nb = nl - l0 < ACC_LINES ? nl - l0 : ACC_LINES;
+        if (tid < nb) {
+            const int32_t j = lines[l0 + tid];
+            s_b[tid] = row_ptr[j]; s_e[tid] = row_ptr[j + 1]; s_w[tid] = sidf[j]; s_f[tid] = flags[j];
+        }
+        __syncthreads();
+        for (int i = 0; i < nb; i++) {
+            const int64_t b = s_b[i], e = s_e[i];
+            const double wgt = s_w[i];
+            if (s_f[i]) {
+                // a sample repeats inside this line: keep the line's own order
                 if (tid == 0)
                     for (int64_t t = b; t < e; t++) {
-                        int32_t id = ids[t];
-                        acc[id] = __dadd_rn(acc[id], __dmul_rn((double)cov[t], wgt));
+                        const uint32_t off = (uint32_t)((int64_t)ids[t] - r_lo);
+                        if (off < span) acc[off] = __dadd_rn(acc[off], __dmul_rn((double)cov[t], wgt));
                     }
             } else {
+                // every sample at most once: the lanes touch distinct cells of the tile
                 for (int64_t t = b + tid; t < e; t += ACC_THREADS) {
-                    int32_t id = ids[t];
+                    const uint32_t off = (uint32_t)((int64_t)ids[t] - r_lo);
                     // tf_idf = cov * idf (one rounding), then += (one rounding): morna.py:384-388
-                    acc[id] = __dadd_rn(acc[id], __dmul_rn((double)cov[t], wgt));
+                    if (off < span) acc[off] = __dadd_rn(acc[off], __dmul_rn((double)cov[t], wgt));
                 }
             }
             __syncthreads();   // the next line of this column may touch the same cells
         }
-        __syncthreads();       // s_list / s_wcnt reuse
     }
+    double *out = colacc + (int64_t)c * n_items + r_lo;
+    for (int i = tid; i < (int)span; i += ACC_THREADS) out[i] = acc[i];
 }
 
 // --------------------------------------------------- fp64 [D][N] -> fp32 [N][dpad]
@@ -202,33 +274,21 @@ int hash_keys_device(morna_index *h, const uint8_t *key_bytes, const int64_t *ke
     DevBuf<uint8_t> dk;
     DevBuf<int64_t> doff;
     DevBuf<int32_t> dh, dc, ds;
-    int rc = MORNA_OK;
-    if ((rc = dk.alloc((size_t)nbytes)) || (rc = doff.alloc((size_t)J + 1)) || (rc = dh.alloc((size_t)J)) ||
-        (rc = dc.alloc((size_t)J)) || (rc = ds.alloc((size_t)J)))
-        goto done;
-#define HASH_TRY(e)                                                  \
-    if ((e) != hipSuccess) {                                         \
-        set_error("%s failed: %s", #e, hipGetErrorString(hipGetLastError())); \
-        rc = MORNA_E_HIP;                                            \
-        goto done;                                                   \
-    }
-    HASH_TRY(hipMemcpyAsync(dk.p, key_bytes, (size_t)nbytes, hipMemcpyHostToDevice, h->stream));
-    HASH_TRY(hipMemcpyAsync(doff.p, key_off, (size_t)(J + 1) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    MORNA_TRY(dk.alloc((size_t)nbytes));
+    MORNA_TRY(doff.alloc((size_t)J + 1));
+    MORNA_TRY(dh.alloc((size_t)J));
+    MORNA_TRY(dc.alloc((size_t)J));
+    MORNA_TRY(ds.alloc((size_t)J));
+    HIP_TRY(hipMemcpyAsync(dk.p, key_bytes, (size_t)nbytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(doff.p, key_off, (size_t)(J + 1) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(hash_keys_kernel, dim3((unsigned)((J + 255) / 256)), dim3(256), 0, h->stream, dk.p, doff.p,
-                       J, h->dim, (const double *)nullptr, dc.p, (double *)nullptr, dh.p, ds.p);
-    HASH_TRY(hipGetLastError());
-    if (hash_out) HASH_TRY(hipMemcpyAsync(hash_out, dh.p, (size_t)J * 4, hipMemcpyDeviceToHost, h->stream));
-    if (col_out) HASH_TRY(hipMemcpyAsync(col_out, dc.p, (size_t)J * 4, hipMemcpyDeviceToHost, h->stream));
-    if (sign_out) HASH_TRY(hipMemcpyAsync(sign_out, ds.p, (size_t)J * 4, hipMemcpyDeviceToHost, h->stream));
-    HASH_TRY(hipStreamSynchronize(h->stream));
-#undef HASH_TRY
-done:
-    dk.release();
-    doff.release();
-    dh.release();
-    dc.release();
-    ds.release();
-    return rc;
+                       J, h->dim, (const double *)nullptr, dc.p, (double *)nullptr, dh.p, ds.p, (int32_t *)nullptr);
+    HIP_TRY(hipGetLastError());
+    if (hash_out) HIP_TRY(hipMemcpyAsync(hash_out, dh.p, (size_t)J * 4, hipMemcpyDeviceToHost, h->stream));
+    if (col_out) HIP_TRY(hipMemcpyAsync(col_out, dc.p, (size_t)J * 4, hipMemcpyDeviceToHost, h->stream));
+    if (sign_out) HIP_TRY(hipMemcpyAsync(sign_out, ds.p, (size_t)J * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MORNA_OK;
 }
 
 int build_features(morna_index *h, int64_t n_items)
@@ -243,61 +303,58 @@ int build_features(morna_index *h, int64_t n_items)
     }
     const int64_t J = h->J;
     const int32_t D = h->dim;
-    DevBuf<int32_t> col;
+    if (J > INT32_MAX) {
+        set_error("build_features: %lld junction lines exceed the 2^31 limit", (long long)J);
+        return MORNA_E_INVALID;
+    }
+    DevBuf<int32_t> col, col_count, col_off, col_lines;
     DevBuf<double> sidf, colacc;
-    DevBuf<uint8_t> serial;
-    int rc = MORNA_OK;
+    DevBuf<uint8_t> flags;
     // algorithmic bytes of this pass: 8*nnz + keys + 8*J + 4*N*D
     const int64_t alg_bytes = 8 * h->nnz + h->key_bytes_n + 8 * J + 4 * n_items * (int64_t)D;
-    if ((rc = col.alloc((size_t)J)) || (rc = sidf.alloc((size_t)J)) || (rc = serial.alloc((size_t)J)) ||
-        (rc = colacc.alloc((size_t)D * (size_t)n_items)) || (rc = h->X.alloc((size_t)n_items * h->dpad)))
-        goto done;
+    MORNA_TRY(col.alloc((size_t)J));
+    MORNA_TRY(sidf.alloc((size_t)J));
+    MORNA_TRY(flags.alloc((size_t)J));
+    MORNA_TRY(col_count.alloc((size_t)D));
+    MORNA_TRY(col_off.alloc((size_t)D + 1));
+    MORNA_TRY(col_lines.alloc((size_t)J));
+    MORNA_TRY(colacc.alloc((size_t)D * (size_t)n_items));
+    MORNA_TRY(h->X.alloc((size_t)n_items * h->dpad));
     {
         ScopedTimer tm(h, MORNA_T_FEATURES, alg_bytes);
-        hipError_t e;
-        if ((e = hipMemsetAsync(colacc.p, 0, (size_t)D * (size_t)n_items * sizeof(double), h->stream)) != hipSuccess) {
-            set_error("memset colacc: %s", hipGetErrorString(e));
-            rc = MORNA_E_HIP;
-            goto done;
-        }
+        HIP_TRY(hipMemsetAsync(col_count.p, 0, (size_t)D * 4, h->stream));
         if (J > 0) {
             hipLaunchKernelGGL(hash_keys_kernel, dim3((unsigned)((J + 255) / 256)), dim3(256), 0, h->stream,
                                h->s_keys.p, h->s_key_off.p, J, D, h->s_idf.p, col.p, sidf.p, (int32_t *)nullptr,
-                               (int32_t *)nullptr);
-            int fl_blocks = (int)std::min<int64_t>((J + 3) / 4, 256 * 8);
-            hipLaunchKernelGGL(line_flags_kernel, dim3(fl_blocks), dim3(256), 0, h->stream, h->s_row_ptr.p,
-                               h->s_ids.p, J, serial.p);
-            hipLaunchKernelGGL(accumulate_kernel, dim3(D), dim3(ACC_THREADS), 0, h->stream, col.p, sidf.p, serial.p,
-                               h->s_row_ptr.p, h->s_ids.p, h->s_cov.p, J, n_items, colacc.p);
+                               (int32_t *)nullptr, col_count.p);
+            const int64_t n_words = (n_items + 31) / 32;
+            if (n_words <= FLAG_MAX_WORDS) {
+                const int fl_blocks = (int)std::min<int64_t>(J, 256 * 4);
+                hipLaunchKernelGGL(line_flags_kernel, dim3(fl_blocks), dim3(256), (size_t)n_words * 4, h->stream,
+                                   h->s_row_ptr.p, h->s_ids.p, J, (int32_t)n_words, flags.p);
+            } else {
+                // the sample bitmap does not fit LDS: take the order-preserving serial path for every line
+                HIP_TRY(hipMemsetAsync(flags.p, 1, (size_t)J, h->stream));
+            }
         }
+        hipLaunchKernelGGL(col_scan_kernel, dim3(1), dim3(1024), 0, h->stream, col_count.p, D, col_off.p);
+        hipLaunchKernelGGL(col_fill_kernel, dim3(D), dim3(ACC_THREADS), 0, h->stream, col.p, J, col_off.p, col_lines.p);
+        const unsigned tiles = (unsigned)((n_items + ACC_TILE - 1) / ACC_TILE);
+        hipLaunchKernelGGL(accumulate_kernel, dim3(tiles, D), dim3(ACC_THREADS), 0, h->stream, col_off.p, col_lines.p,
+                           sidf.p, flags.p, h->s_row_ptr.p, h->s_ids.p, h->s_cov.p, n_items, colacc.p);
         dim3 tg((unsigned)((n_items + TT - 1) / TT), (unsigned)((h->dpad + TT - 1) / TT));
         hipLaunchKernelGGL(transpose_convert_kernel, tg, dim3(256), 0, h->stream, colacc.p, n_items, D, h->dpad,
                            h->X.p);
-        if ((e = hipGetLastError()) != hipSuccess) {
-            set_error("feature kernels: %s", hipGetErrorString(e));
-            rc = MORNA_E_HIP;
-            goto done;
-        }
+        HIP_TRY(hipGetLastError());
         h->n_items = n_items;
         h->host_n = 0;
         h->host_rows.clear();
         h->host_dirty = false;
         h->built = false;
-        if ((rc = compute_norms(h))) goto done;
+        MORNA_TRY(compute_norms(h));
     }
-    {
-        hipError_t e = hipStreamSynchronize(h->stream);   // scratch buffers are freed below
-        if (e != hipSuccess) {
-            set_error("build_features: %s", hipGetErrorString(e));
-            rc = MORNA_E_HIP;
-        }
-    }
-done:
-    col.release();
-    sidf.release();
-    serial.release();
-    colacc.release();
-    return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));   // scratch buffers are freed on return
+    return MORNA_OK;
 }
 
 }  // namespace morna
