@@ -186,10 +186,75 @@ __global__ __launch_bounds__(TM_THREADS) void two_means_kernel(const float *__re
 #define SP_WAVES (SP_THREADS / WAVE)
 #define SP_ROWS 64      // rows per workgroup
 
-// rows of task `ti` at positions [chunk*SP_ROWS, ...) get their side
+// ---- XCD-aware launch order of the split kernel ---------------------------------
+// Every row is read once per TREE at every level, and a node's item list is sorted
+// by id (stable partitions of the identity permutation).  Chunks are therefore
+// ordered by the id of their first row, and the sorted list is cut into 8
+// contiguous runs, one per XCD (workgroup b runs on XCD b % 8): the ~n_trees
+// chunks that need the same rows then run back to back on ONE XCD and find them in
+// its L2 instead of HBM.  The order only affects speed, never results.
+
+#define SCHED_MAX_BUCKETS 65536
+
+__global__ void sched_bucket_kernel(const SplitTask *__restrict__ tasks, int32_t n_tasks, int32_t n_chunks,
+                                    const int32_t *__restrict__ perm, int64_t n_items, int32_t n_buckets,
+                                    int32_t *__restrict__ hist, int2 *__restrict__ info /* [n_chunks] task, bucket */)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    int lo = 0, hi = n_tasks - 1;   // the task owning this chunk (tasks sorted by chunk0)
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (tasks[mid].chunk0 <= c) lo = mid; else hi = mid - 1;
+    }
+    const SplitTask t = tasks[lo];
+    const int pos0 = (c - t.chunk0) * 64;
+    const int64_t first = perm[(int64_t)t.tree * n_items + t.start + pos0];
+    const int b = (int)(first * n_buckets / n_items);
+    atomicAdd(&hist[b], 1);
+    info[c] = make_int2(lo, b);
+}
+
+__global__ __launch_bounds__(1024) void sched_scan_kernel(const int32_t *__restrict__ hist, int32_t n_buckets,
+                                                          int32_t *__restrict__ cursor /* [n_buckets] start offsets */)
+{
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n_buckets + 1023) / 1024;
+    const int lo = tid * per, hi = lo + per < n_buckets ? lo + per : n_buckets;
+    int sum = 0;
+    for (int i = lo; i < hi; i++) sum += hist[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        int v = tid >= o ? s_part[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = tid ? s_part[tid - 1] : 0;
+    for (int i = lo; i < hi; i++) {
+        cursor[i] = run;
+        run += hist[i];
+    }
+}
+
+__global__ void sched_scatter_kernel(const SplitTask *__restrict__ tasks, int32_t n_chunks,
+                                     const int2 *__restrict__ info, int32_t *__restrict__ cursor,
+                                     int2 *__restrict__ sched /* [n_chunks] task, chunk in task */)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const int2 e = info[c];
+    const int pos = atomicAdd(&cursor[e.y], 1);
+    sched[pos] = make_int2(e.x, c - tasks[e.x].chunk0);
+}
+
+// rows [chunk*SP_ROWS, ...) of one task get their side
 __global__ __launch_bounds__(SP_THREADS) void split_kernel(const float *__restrict__ X, int64_t n_items, int32_t dpad,
                                                            const int32_t *__restrict__ perm,
-                                                           const SplitTask *__restrict__ tasks, int32_t n_tasks,
+                                                           const SplitTask *__restrict__ tasks,
+                                                           const int2 *__restrict__ sched, int32_t n_chunks,
                                                            uint32_t seed, const float *__restrict__ hp,
                                                            uint8_t *__restrict__ side, int32_t *__restrict__ ones)
 {
@@ -199,15 +264,14 @@ __global__ __launch_bounds__(SP_THREADS) void split_kernel(const float *__restri
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const int nvec = dpad / 4;
-    // find the task owning this chunk (tasks sorted by chunk0)
-    int lo = 0, hi = n_tasks - 1;
-    const int chunk = blockIdx.x;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (tasks[mid].chunk0 <= chunk) lo = mid; else hi = mid - 1;
-    }
+    // workgroup b runs on XCD b % 8: XCD x walks the x-th eighth of the sorted chunk list
+    const int per_xcd = (n_chunks + 7) / 8;
+    const int si = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || si >= n_chunks) return;
+    const int2 se = sched[si];
+    const int lo = se.x;
     const SplitTask t = tasks[lo];
-    const int pos0 = (chunk - t.chunk0) * SP_ROWS;
+    const int pos0 = se.y * SP_ROWS;
     const int nrows = (t.count - pos0) < SP_ROWS ? (t.count - pos0) : SP_ROWS;
 
     const float4 *hsrc = (const float4 *)(hp + (int64_t)t.slot * dpad);
@@ -355,6 +419,12 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
     DevBuf<SplitTask> d_tasks;
     MORNA_TRY(tmp.alloc((size_t)n_trees * N));
     MORNA_TRY(side.alloc((size_t)n_trees * N));
+    // launch-order scratch of the split kernel: buckets of 32 row ids
+    DevBuf<int32_t> d_hist, d_cursor;
+    DevBuf<int2> d_info, d_sched;
+    const int32_t n_buckets = (int32_t)std::min<int64_t>(SCHED_MAX_BUCKETS, std::max<int64_t>(1, (N + 31) / 32));
+    MORNA_TRY(d_hist.alloc((size_t)n_buckets));
+    MORNA_TRY(d_cursor.alloc((size_t)n_buckets));
     {
         const int64_t total = (int64_t)n_trees * N;
         hipLaunchKernelGGL(iota_perm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->perm.p, N, total);
@@ -437,10 +507,22 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                                    h->X.p, h->norm2.p, N, dpad, h->perm.p, d_tasks.p, seed, hp_level);
             }
             {
+                // launch order: chunks sorted by first row id, one contiguous run per XCD
+                if ((rc = d_info.alloc((size_t)n_chunks)) || (rc = d_sched.alloc((size_t)n_chunks))) { cleanup(); return rc; }
+                F_TRY(hipMemsetAsync(d_hist.p, 0, (size_t)n_buckets * 4, h->stream));
+                const unsigned cb = (unsigned)((n_chunks + 255) / 256);
+                hipLaunchKernelGGL(sched_bucket_kernel, dim3(cb), dim3(256), 0, h->stream, d_tasks.p, A, n_chunks, h->perm.p, N,
+                                   n_buckets, d_hist.p, d_info.p);
+                hipLaunchKernelGGL(sched_scan_kernel, dim3(1), dim3(1024), 0, h->stream, d_hist.p, n_buckets, d_cursor.p);
+                hipLaunchKernelGGL(sched_scatter_kernel, dim3(cb), dim3(256), 0, h->stream, d_tasks.p, n_chunks, d_info.p,
+                                   d_cursor.p, d_sched.p);
+            }
+            {
                 // algorithmic bytes: 4*D*sum|node| + 4*D*#split nodes
                 ScopedTimer tm(h, MORNA_T_SPLIT, 4 * (int64_t)D * (rows + A));
-                hipLaunchKernelGGL(split_kernel, dim3((unsigned)n_chunks), dim3(SP_THREADS), (size_t)dpad * 4, h->stream,
-                                   h->X.p, N, dpad, h->perm.p, d_tasks.p, A, seed, hp_level, side.p, d_ones.p);
+                const unsigned grid = 8u * (unsigned)((n_chunks + 7) / 8);
+                hipLaunchKernelGGL(split_kernel, dim3(grid), dim3(SP_THREADS), (size_t)dpad * 4, h->stream, h->X.p, N, dpad,
+                                   h->perm.p, d_tasks.p, d_sched.p, n_chunks, seed, hp_level, side.p, d_ones.p);
             }
             F_TRY(hipGetLastError());
             h_ones.resize((size_t)A);
