@@ -1,0 +1,115 @@
+"""`morna index` / `morna search` command line on the MI355X library.
+
+Mirrors the reference's parser and dispatch (commanderson/morna
+morna.py:867-1054, 1338-1484): same subcommands, flag names, defaults and output
+format for the hot path.  Not carried over: `junctions`,
+the convergence back-off loop (-c / -ch), the metadata database (-m) and the
+junctions-by-sample shards (-b is accepted and ignored).
+
+    python -m morna_amd.cli index --intropolis junctions.tsv.gz -x idx -s 9662 --n-trees 10
+    python -m morna_amd.cli search -x idx -q 1234 -d
+    cat query.bed | python -m morna_amd.cli search -x idx -f bed --exact -d
+"""
+import argparse
+import sys
+
+_help_intro = """morna searches for known RNA-seq samples with exon-exon junction expression
+patterns similar to those in a query sample (MI355X build of the index/search hot path).
+"""
+
+
+def add_search_parameters(subparser):
+    subparser.add_argument('-x', '--basename', metavar='<idx>', type=str, required=True,
+                           help='path to junction index basename for search')
+    subparser.add_argument('-v', '--verbose', action='store_const', const=True, default=False, help='be talkative')
+    subparser.add_argument('--search-k', metavar='<int>', type=int, required=False, default=100,
+                           help='a larger value makes for more accurate search')
+    subparser.add_argument('-f', '--format', metavar='<choice>', type=str, required=False, default='sam',
+                           help='one of {sam, bed, raw}')
+    subparser.add_argument('-d', '--distances', action='store_const', const=True, default=False,
+                           help='include distances to nearest neighbors')
+    subparser.add_argument('-q', '--query-id', metavar='<int>', type=int, required=False, default=None,
+                           help='search for nearest neighbors to the sample already in the index with this sample id')
+    subparser.add_argument('-e', '--exact', action='store_const', const=True, default=False,
+                           help='exact nearest neighbor search within the morna index')
+    subparser.add_argument('-r', '--results', metavar='<int>', type=int, required=False, default=20,
+                           help='the number of nearest neighbor results to return')
+    subparser.add_argument('-rl', '--rawlist', action='store_const', const=True, default=False,
+                           help='regurgitate junction list for input sample instead of performing search')
+    subparser.add_argument('--device', type=int, default=0, help='HIP device ordinal')
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description=_help_intro)
+    subparsers = parser.add_subparsers(dest='subparser_name',
+                                       help='subcommands; add "-h" or "--help" after a subcommand for its parameters')
+    index_parser = subparsers.add_parser('index', help='creates a morna index')
+    search_parser = subparsers.add_parser('search', help='searches a morna index')
+    index_parser.add_argument('--intropolis', metavar='<file>', type=str, required=True,
+                              help='path to gzipped file recording junctions across samples in intropolis format')
+    index_parser.add_argument('-x', '--basename', metavar='<str>', type=str, required=False, default='morna',
+                              help='basename path of junction index files to create')
+    index_parser.add_argument('--features', metavar='<int>', type=int, required=False, default=3000,
+                              help='dimension of feature space')
+    index_parser.add_argument('--n-trees', metavar='<int>', type=int, required=False, default=200,
+                              help='number of annoy trees')
+    index_parser.add_argument('-s', '--sample-count', metavar='<int>', type=int, required=False, default=None,
+                              help='optionally specify number of unique samples to speed indexing')
+    index_parser.add_argument('-t', '--sample-threshold', metavar='<int>', type=int, required=False, default=100,
+                              help='minimum number of samples in which a junction should appear')
+    index_parser.add_argument('-b', '--buffer-size', metavar='<int>', type=int, required=False, default=1024,
+                              help='accepted for compatibility; the per-sample junction database is out of scope')
+    index_parser.add_argument('-v', '--verbose', action='store_const', const=True, default=False, help='be talkative')
+    index_parser.add_argument('--device', type=int, default=0, help='HIP device ordinal')
+    add_search_parameters(search_parser)
+    return parser
+
+
+def main(argv=None, stdin=None, stdout=None):
+    args = build_parser().parse_args(argv)
+    stdin = stdin or sys.stdin
+    stdout = stdout or sys.stdout
+    if args.subparser_name == 'index':
+        from .index import go_index
+        go_index(args.intropolis, args.basename, args.features, args.n_trees, args.sample_count,
+                 args.sample_threshold, args.buffer_size, args.verbose, None, device=args.device)
+        return 0
+    if args.subparser_name != 'search':
+        build_parser().print_help()
+        return 2
+    from .search import MornaSearch, results_output
+    from .streams import junctions_from_bed_stream, junctions_from_raw_stream, junctions_from_sam_stream
+    searcher = MornaSearch(basename=args.basename, device=args.device)
+    if args.query_id is not None:                              # morna.py:1358-1365
+        results = searcher.search_member_n(args.query_id, args.results, args.search_k,
+                                           include_distances=args.distances)
+        results_output(results, stdout)
+        return 0
+    if args.format == "sam":
+        junction_generator = junctions_from_sam_stream(stdin)
+    elif args.format == "bed":
+        junction_generator = junctions_from_bed_stream(stdin)
+    else:
+        assert args.format == "raw"
+        junction_generator = junctions_from_raw_stream(stdin)
+    if args.rawlist:
+        for junction in junction_generator:
+            stdout.write(str(junction) + "\n")
+        return 0
+    for i, junction in enumerate(junction_generator):          # morna.py:1455-1472
+        string_junction = " ".join(str(_) for _ in junction[:3])
+        if args.verbose and i % 1000 == 0:
+            sys.stderr.write(str(i) + " junctions into query sample\r")
+        if string_junction in searcher.sample_frequencies:
+            searcher.update_query(junction)
+    searcher.finalize_query()
+    if args.exact:
+        results = searcher.exact_search_nn(args.results, include_distances=args.distances)
+    else:
+        results = searcher.search_nn(args.results, args.search_k, include_distances=args.distances)
+    results_output(results, stdout)
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -1,0 +1,99 @@
+"""Host-side mirror of the reference interface: parsers, tokenising, the
+vectorised add_junction pre-pass.  No GPU needed."""
+import io
+
+import numpy as np
+import pytest
+
+from morna_amd import index as mindex
+from morna_amd import streams
+from oracle import morna_ref
+
+
+def test_count_samples_and_tokenize(embedded):
+    assert mindex.count_samples(embedded["generic"]) == 10          # morna.py:1140-1149
+    k, s, c = mindex.tokenize_line(embedded["generic"][16])
+    assert k == "chr10 102161920 102162275"
+    assert s == list(range(1, 11)) and c == [2, 1, 1, 2, 2, 1, 2, 3, 8, 2]
+    assert mindex.tokenize_line(embedded["generic"][16]) == morna_ref.tokenize_line(embedded["generic"][16])
+
+
+def _tok(lines):
+    keys, rp, s, c = [], [0], [], []
+    for ln in lines:
+        k, ss, cc = mindex.tokenize_line(ln)
+        keys.append(k)
+        s += ss
+        c += cc
+        rp.append(len(s))
+    return keys, np.array(rp, np.int64), np.array(s, np.int64), np.array(c, np.int64)
+
+
+@pytest.mark.parametrize("name", ["simple", "lossy", "lose_sample"])
+def test_prepare_csr_equals_reference_prepass(embedded, name):
+    """threshold, cumulative freq, first-seen ids and idf as MornaIndex.add_junction computes them"""
+    spec = embedded["expected"][name]
+    lines = embedded[spec["input"]]
+    ref = morna_ref.go_index_lines(lines, 128, spec["sample_count"], spec["sample_threshold"])
+    keys, rp, s, c = _tok(lines)
+    prep = mindex.prepare_csr(keys, rp, s, c, spec["sample_count"], spec["sample_threshold"])
+    assert prep["n_items"] == ref.new_internal_id == spec["n_items"]
+    assert prep["skipped"] == ref.skipped
+    assert prep["ext_ids"].tolist() == sorted(ref.internal_id_map, key=ref.internal_id_map.get)
+    assert prep["freq"] == dict(ref.sample_frequencies)
+    assert len(prep["idf"]) == len(lines) - ref.skipped
+    assert prep["row_ptr"][-1] == len(prep["ids"]) == len(prep["cov"])
+    assert prep["ids"].max() == prep["n_items"] - 1
+
+
+def test_prepare_csr_duplicate_keys_use_cumulative_frequency():
+    from math import log
+    keys = ["chr1 1 2", "chr1 5 9", "chr1 1 2"]
+    rp = np.array([0, 2, 4, 7])
+    s = np.array([7, 9, 9, 3, 7, 3, 11])
+    c = np.ones(7, np.int64)
+    prep = mindex.prepare_csr(keys, rp, s, c, 20, 1)
+    assert prep["idf"].tolist() == [log(20.0 / 2), log(20.0 / 2), log(20.0 / 5)]      # morna.py:365, 372
+    assert prep["ext_ids"].tolist() == [7, 9, 3, 11]
+    assert prep["ids"].tolist() == [0, 1, 1, 2, 0, 2, 3]
+
+
+def test_raw_stream():
+    got = list(streams.junctions_from_raw_stream(io.StringIO("chr1\t100\t200\t7\nchrX\t5\t9\t1\textra\n")))
+    assert got == [("chr1", 100, 200, 7), ("chrX", 5, 9, 1)]
+
+
+def test_bed_stream():
+    # TopHat-style junctions.bed: blocks (size 10 at 0) and (size 20 at 110) of a feature starting at 1000
+    line = "chr2\t1000\t1130\tJUNC1\t42\t+\t1000\t1130\t255,0,0\t2\t10,20\t0,110\n"
+    assert list(streams.junctions_from_bed_stream(io.StringIO(line))) == [("chr2", 1011, 1110, 42)]
+    # three blocks -> two junctions; trailing commas; a short line is skipped
+    line3 = "chr2\t1000\t1400\tJ\t3\t-\t1000\t1400\t0\t3\t10,20,30,\t0,100,370,\nshort\tline\n"
+    assert list(streams.junctions_from_bed_stream(io.StringIO(line3))) == [("chr2", 1011, 1100, 3),
+                                                                           ("chr2", 1121, 1370, 3)]
+
+
+def test_sam_stream():
+    sam = ("@HD\tVN:1.0\n"
+           "r1\t0\tchr1\t100\t255\t10M50N10M\t*\t0\t0\tACGTACGTACGTACGTACGT\t*\n"        # junction 110..159
+           "r2\t4\tchr1\t100\t255\t10M50N10M\t*\t0\t0\tACGT\t*\n"                         # unmapped
+           "r3\t256\tchr1\t100\t255\t10M50N10M\t*\t0\t0\tACGT\t*\n"                       # secondary
+           "r4\t16\tchr3\t7\t255\t2S5M2I3M100N4M2D6M30N1M\t*\t0\t0\tACGTACGTACGTACGTACGTACG\t*\n"
+           "r5\t0\tchr1\t100\t255\t20M\t*\t0\t0\tACGT\t*\n")                              # unspliced
+    got = list(streams.junctions_from_sam_stream(io.StringIO(sam)))
+    # r4: pos 7; 5M -> 12; 3M -> 15; 100N -> junction (15, 114), pos 115; 4M -> 119; 2D -> 121; 6M -> 127; 30N -> (127, 156)
+    assert got == [("chr1", 110, 159, 1), ("chr3", 15, 114, 1), ("chr3", 127, 156, 1)]
+    with pytest.raises(RuntimeError):
+        list(streams.junctions_from_sam_stream(io.StringIO("r\t0\tc\t1\t255\t5M3X2N5M\t*\t0\t0\tAC\t*\n")))
+    with pytest.raises(IndexError):
+        list(streams.junctions_from_sam_stream(io.StringIO("r\t0\tc\t1\t255\t5M2N5M\n")))
+
+
+def test_cli_parser_defaults_match_reference():
+    from morna_amd.cli import build_parser
+    p = build_parser()
+    a = p.parse_args(["index", "--intropolis", "x.gz"])
+    assert (a.basename, a.features, a.n_trees, a.sample_count, a.sample_threshold, a.buffer_size) == \
+        ("morna", 3000, 200, None, 100, 1024)                         # morna.py:970-1021
+    s = p.parse_args(["search", "-x", "idx"])
+    assert (s.search_k, s.format, s.distances, s.query_id, s.exact, s.results) == (100, "sam", False, None, False, 20)
