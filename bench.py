@@ -182,6 +182,16 @@ def main():
     if rank == 0:
         sp = timers["split"]
         achieved = (sp["bytes"] / 1e9) / (sp["ms"] / 1e3) if sp["ms"] > 0 else 0.0
+        # HBM-side bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes
+        # (scripts/profile_summary.py -> profiles/*_traffic.json); only quoted for the same workload
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_c3_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            if tj.get("config") == {"samples": N, "features": D, "trees": T} and "morna::split_kernel" in tj["kernels"]:
+                traffic = tj["kernels"]["morna::split_kernel"]["hbm_bytes_per_launch"]
+                traffic_src = "profiles/r01_c3_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
         total_samples = n_items * world * args.steps
         out = {
             "metric": "samples indexed/sec (index build + %d queries, k=%d) at %dk x %d" % (Q, k, N // 1000, D),
@@ -206,8 +216,12 @@ def main():
             "roofline": {"kernel": "split_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "launches": sp["launches"] // max(args.steps, 1),
-                         "alg_bytes_per_step": sp["bytes"] // max(args.steps, 1),
-                         "traffic": None},
+                         "alg_bytes_per_launch": sp["bytes"] // max(sp["launches"], 1),
+                         "ms_per_launch": sp["ms"] / max(sp["launches"], 1),
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "note": ("every row is needed once per tree per level; chunks are launched sorted by row id, "
+                                  "one run per XCD, so most of those reads are served by L2: frac > 1 means the "
+                                  "algorithmic bytes exceeded what HBM alone could deliver")},
         }
         if args.verify:
             ids = res[0]

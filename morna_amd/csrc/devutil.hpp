@@ -140,10 +140,32 @@ __device__ inline float wave_sum_xor(float v)
     return v;
 }
 
-// fold of the four per-lane chains, then the butterfly
+// The value lane 0 holds after the xor butterfly 32,16,8,4,2,1 -- same binary tree, same
+// roundings -- computed with VALU cross-lane moves only (v_permlane32_swap, v_permlane16_swap,
+// DPP row_shl) instead of six dependent ds_bpermute round trips, then broadcast to the wave.
+// At stage s only lanes < s matter, and lane l < s needs lane l + s: a half swap, a row swap and
+// four in-row shifts deliver exactly those partners.
+__device__ inline float wave_sum_lane0(float v)
+{
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    unsigned u = __float_as_uint(v);
+    u32x2 r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // r[1], lanes 0-31: lanes 32-63 of u
+    v = v + __uint_as_float(r[1]);
+    u = __float_as_uint(v);
+    r = __builtin_amdgcn_permlane16_swap(u, u, false, false);         // r[1], rows 0/2: rows 1/3 of u
+    v = v + __uint_as_float(r[1]);
+    // row_shl:n -- lane i reads lane i + n of its 16-lane row (0 when out of the row)
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x108, 0xf, 0xf, true));
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xf, 0xf, true));
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x102, 0xf, 0xf, true));
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xf, 0xf, true));
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+// fold of the four per-lane chains, then the butterfly (lane 0's value, broadcast)
 __device__ inline float wave_dot_finish(float a0, float a1, float a2, float a3)
 {
-    return wave_sum_xor((a0 + a1) + (a2 + a3));
+    return wave_sum_lane0((a0 + a1) + (a2 + a3));
 }
 
 #define FMA4(acc, xv, yv)                         \

@@ -21,6 +21,7 @@
 // level get consecutive ids, exactly as oracle mode 1 does.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -180,6 +181,121 @@ __global__ __launch_bounds__(TM_THREADS) void two_means_kernel(const float *__re
     for (int v = tid; v < nvec; v += TM_THREADS) out[v] = ((float4 *)p)[v];
 }
 
+// ---- two_means, one WAVE per node, everything in registers ------------------------
+// For dpad <= 3072 the two centroids, the current row and the prefetched next row fit the
+// register file (4 x NV float4 per lane): no LDS, no workgroup barrier in the 200-step loop.
+// Same arithmetic, same order as two_means_kernel (the lane owns the same elements).
+
+#define EW4(dst, expr_x, expr_y, expr_z, expr_w) \
+    do { (dst).x = (expr_x); (dst).y = (expr_y); (dst).z = (expr_z); (dst).w = (expr_w); } while (0)
+
+template <int NV>
+__device__ inline float reg_dot(const float4 (&a)[NV], const float4 (&b)[NV])
+{
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) FMA4(s, a[k], b[k]);   // pad elements are 0 in both: fmaf(0, 0, s) == s
+    return wave_dot_finish(s0, s1, s2, s3);
+}
+
+template <int NV>
+__device__ inline void reg_load_row(const float *row, int nvec, int lane, float4 (&x)[NV])
+{
+    const float4 *xp = (const float4 *)row;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const int i = lane + k * WAVE;
+        x[k] = i < nvec ? xp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+template <int NV>
+__device__ inline void reg_normalize(float4 (&v)[NV])
+{
+    const float norm = sqrtf(reg_dot<NV>(v, v));
+    if (norm > 0.f) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) EW4(v[k], v[k].x / norm, v[k].y / norm, v[k].z / norm, v[k].w / norm);
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void two_means_wave_kernel(const float *__restrict__ X, const float *__restrict__ norm2,
+                                                             int64_t n_items, int32_t dpad,
+                                                             const int32_t *__restrict__ perm,
+                                                             const SplitTask *__restrict__ tasks, int32_t n_tasks,
+                                                             uint32_t seed, float *__restrict__ hp)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int ti = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
+    if (ti >= n_tasks) return;   // no barrier below: waves are independent
+    const SplitTask t = tasks[ti];
+    const int nvec = dpad / 4;
+    const int32_t *items = perm + (int64_t)t.tree * n_items + t.start;
+    Kiss32 rng(node_seed(seed, (uint32_t)t.tree, (uint32_t)t.level, (uint32_t)t.start, (uint32_t)t.attempt));
+
+    uint32_t i = rng.index((uint32_t)t.count);
+    uint32_t j = rng.index((uint32_t)t.count - 1u);
+    j += (j >= i);
+    float4 p[NV], q[NV], x[NV], xn[NV];
+    reg_load_row<NV>(X + (int64_t)items[i] * dpad, nvec, lane, p);
+    reg_load_row<NV>(X + (int64_t)items[j] * dpad, nvec, lane, q);
+    reg_normalize<NV>(p);
+    reg_normalize<NV>(q);
+    float pp = reg_dot<NV>(p, p), qq = reg_dot<NV>(q, q);
+    uint32_t k = rng.index((uint32_t)t.count);
+    int32_t it = items[k];
+    reg_load_row<NV>(X + (int64_t)it * dpad, nvec, lane, x);
+
+    int ic = 1, jc = 1;
+    for (int l = 0; l < TM_ITERS; l++) {
+        const bool more = l + 1 < TM_ITERS;
+        int32_t it_next = it;
+        if (more) {   // the Kiss32 stream does not depend on data: fetch row l+1 while row l is used
+            it_next = items[rng.index((uint32_t)t.count)];
+            reg_load_row<NV>(X + (int64_t)it_next * dpad, nvec, lane, xn);
+        }
+        const float nk2 = norm2[it];
+        const float di = (float)ic * ang_dist(pp, nk2, reg_dot<NV>(p, x));
+        const float dj = (float)jc * ang_dist(qq, nk2, reg_dot<NV>(q, x));
+        const float norm = sqrtf(nk2);
+        if (norm > 0.f) {
+            if (di < dj) {
+                const float f0 = (float)ic, f1 = (float)(ic + 1);
+#pragma unroll
+                for (int kk = 0; kk < NV; kk++)
+                    EW4(p[kk], (p[kk].x * f0 + x[kk].x / norm) / f1, (p[kk].y * f0 + x[kk].y / norm) / f1,
+                        (p[kk].z * f0 + x[kk].z / norm) / f1, (p[kk].w * f0 + x[kk].w / norm) / f1);
+                pp = reg_dot<NV>(p, p);
+                ic++;
+            } else if (dj < di) {
+                const float f0 = (float)jc, f1 = (float)(jc + 1);
+#pragma unroll
+                for (int kk = 0; kk < NV; kk++)
+                    EW4(q[kk], (q[kk].x * f0 + x[kk].x / norm) / f1, (q[kk].y * f0 + x[kk].y / norm) / f1,
+                        (q[kk].z * f0 + x[kk].z / norm) / f1, (q[kk].w * f0 + x[kk].w / norm) / f1);
+                qq = reg_dot<NV>(q, q);
+                jc++;
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int kk = 0; kk < NV; kk++) x[kk] = xn[kk];
+            it = it_next;
+        }
+    }
+    // create_split: n = normalize(p - q)
+#pragma unroll
+    for (int kk = 0; kk < NV; kk++) EW4(p[kk], p[kk].x - q[kk].x, p[kk].y - q[kk].y, p[kk].z - q[kk].z, p[kk].w - q[kk].w);
+    reg_normalize<NV>(p);
+    float4 *out = (float4 *)(hp + (int64_t)t.slot * dpad);
+#pragma unroll
+    for (int kk = 0; kk < NV; kk++) {
+        const int idx = lane + kk * WAVE;
+        if (idx < nvec) out[idx] = p[kk];
+    }
+}
+
 // ---------------------------------------------------------------- split kernel
 
 #define SP_THREADS 256
@@ -294,6 +410,133 @@ __global__ __launch_bounds__(SP_THREADS) void split_kernel(const float *__restri
     if (lane == 0 && my_ones) atomicAdd(&s_ones, my_ones);
     __syncthreads();
     if (tid == 0 && s_ones) atomicAdd(&ones[lo], s_ones);
+}
+
+// ---- shallow levels: row-window form of the split kernel ---------------------------
+// While a tree has at most RW_SLOTS / G split nodes, a workgroup takes a WINDOW of 64
+// consecutive row ids and a GROUP of G trees: the <= RW_SLOTS hyperplanes those trees
+// can need sit in LDS, each wave loads a row ONCE into registers and dots it against
+// the hyperplane of its node in every tree of the group.  L2 -> CU traffic per
+// (row, tree) drops from one row to 1/G row; same wave_dot order, same results.
+
+#define RW_THREADS 512
+#define RW_WAVES (RW_THREADS / WAVE)
+#define RW_ROWS 64
+#define RW_SLOTS 8
+
+// inverse of the permutation restricted to the tasks: row -> (task index, position in segment)
+__global__ void invert_kernel(const SplitTask *__restrict__ tasks, const int2 *__restrict__ info /* task per chunk */,
+                              int32_t n_chunks, const int32_t *__restrict__ perm, int64_t n_items,
+                              int32_t *__restrict__ row_task, int32_t *__restrict__ row_pos)
+{
+    const int c = blockIdx.x;
+    if (c >= n_chunks) return;
+    const int a = info[c].x;
+    const SplitTask t = tasks[a];
+    const int p = (c - t.chunk0) * 64 + threadIdx.x;
+    if (p < t.count) {
+        const int64_t row = perm[(int64_t)t.tree * n_items + t.start + p];
+        row_task[(int64_t)t.tree * n_items + row] = a;
+        row_pos[(int64_t)t.tree * n_items + row] = p;
+    }
+}
+
+template <int NV>   // float4 per lane that hold one row: ceil(dpad / 256)
+__global__ __launch_bounds__(RW_THREADS) void split_rw_kernel(
+    const float *__restrict__ X, int64_t n_items, int32_t dpad, const SplitTask *__restrict__ tasks,
+    const int32_t *__restrict__ tree_first /* [n_trees + 1] */, int32_t n_trees, int32_t G,
+    const int32_t *__restrict__ row_task, const int32_t *__restrict__ row_pos, uint32_t seed,
+    const float *__restrict__ hp, uint8_t *__restrict__ side, int32_t *__restrict__ ones, int32_t n_windows,
+    int32_t n_groups)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *hs = (float4 *)smem;   // [RW_SLOTS][nvec]
+    __shared__ int s_ones[RW_SLOTS], s_start[RW_SLOTS];
+    __shared__ uint32_t s_seed[RW_SLOTS];
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int nvec = dpad / 4;
+    // workgroup b runs on XCD b % 8: all tree groups of one window stay on one XCD, back to back
+    const int x = blockIdx.x & 7, r = blockIdx.x >> 3;
+    const int win = (r / n_groups) * 8 + x, g = r % n_groups;
+    if (win >= n_windows) return;
+    const int t0 = g * G, t1 = (t0 + G) < n_trees ? (t0 + G) : n_trees;
+    const int a0 = tree_first[t0], nslots = tree_first[t1] - a0;   // <= RW_SLOTS by construction
+    for (int s = 0; s < nslots; s++) {
+        const float4 *src = (const float4 *)(hp + (int64_t)tasks[a0 + s].slot * dpad);
+        for (int v = tid; v < nvec; v += RW_THREADS) hs[s * nvec + v] = src[v];
+    }
+    if (tid < nslots) {
+        const SplitTask t = tasks[a0 + tid];
+        s_ones[tid] = 0;
+        s_start[tid] = t.start;
+        s_seed[tid] = node_seed(seed, (uint32_t)t.tree, (uint32_t)t.level, (uint32_t)t.start, (uint32_t)t.attempt);
+    }
+    __syncthreads();
+    if (nslots > 0) {
+        const int ng = t1 - t0;
+        const int64_t row_base = (int64_t)win * RW_ROWS;
+        // a row and its (task, position) per tree of the group are fetched one row ahead
+        auto load_row = [&](int rr, float4(&xr)[NV], int &ma, int &mp) {
+            const int64_t row = row_base + rr;
+            const float4 *xp = (const float4 *)(X + row * dpad);
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                const int i = lane + k * WAVE;
+                xr[k] = i < nvec ? xp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            ma = -1;
+            mp = 0;
+            if (lane < ng) {
+                ma = row_task[(int64_t)(t0 + lane) * n_items + row];
+                mp = row_pos[(int64_t)(t0 + lane) * n_items + row];
+            }
+        };
+        auto process = [&](const float4(&xr)[NV], int ma, int mp) {
+            for (int gi = 0; gi < ng; gi++) {
+                const int a = __shfl(ma, gi, WAVE);   // same for the whole wave
+                if (a < 0) continue;
+                const int p = __shfl(mp, gi, WAVE);
+                const int s = a - a0;
+                const float4 *hv = hs + s * nvec;
+                float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+#pragma unroll
+                for (int k = 0; k < NV; k++) {
+                    const int i = lane + k * WAVE;
+                    if (i < nvec) {
+                        const float4 h4 = hv[i];
+                        FMA4(c, xr[k], h4);
+                    }
+                }
+                const float d = wave_dot_finish(c0, c1, c2, c3);
+                const int sd = d != 0.f ? (d > 0.f) : pos_flip(s_seed[s], (uint32_t)p);
+                if (lane == 0) {
+                    side[(int64_t)(t0 + gi) * n_items + s_start[s] + p] = (uint8_t)sd;
+                    if (sd) atomicAdd(&s_ones[s], 1);
+                }
+            }
+        };
+        auto valid = [&](int rr) { return rr < RW_ROWS && row_base + rr < n_items; };
+        float4 xa[NV], xb[NV];
+        int ma_a = -1, mp_a = 0, ma_b = -1, mp_b = 0;
+        int rr = w;
+        if (valid(rr)) {
+            load_row(rr, xa, ma_a, mp_a);
+            for (;;) {
+                const bool vb = valid(rr + RW_WAVES);
+                if (vb) load_row(rr + RW_WAVES, xb, ma_b, mp_b);
+                process(xa, ma_a, mp_a);
+                if (!vb) break;
+                const bool va = valid(rr + 2 * RW_WAVES);
+                if (va) load_row(rr + 2 * RW_WAVES, xa, ma_a, mp_a);
+                process(xb, ma_b, mp_b);
+                if (!va) break;
+                rr += 2 * RW_WAVES;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < nslots && s_ones[tid]) atomicAdd(&ones[a0 + tid], s_ones[tid]);
 }
 
 // random sides for nodes whose best split is still > 0.99 imbalanced
@@ -425,6 +668,9 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
     const int32_t n_buckets = (int32_t)std::min<int64_t>(SCHED_MAX_BUCKETS, std::max<int64_t>(1, (N + 31) / 32));
     MORNA_TRY(d_hist.alloc((size_t)n_buckets));
     MORNA_TRY(d_cursor.alloc((size_t)n_buckets));
+    // row-window form of the shallow levels: inverse permutation per tree
+    DevBuf<int32_t> row_task, row_pos, d_tree_first;
+    std::vector<int32_t> tree_first;
     {
         const int64_t total = (int64_t)n_trees * N;
         hipLaunchKernelGGL(iota_perm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->perm.p, N, total);
@@ -503,8 +749,20 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             F_TRY(hipMemsetAsync(d_ones.p, 0, (size_t)A * 4, h->stream));
             {
                 ScopedTimer tm(h, MORNA_T_TWO_MEANS, 4 * (int64_t)D * (TM_ITERS + 2) * A);
-                hipLaunchKernelGGL(two_means_kernel, dim3((unsigned)A), dim3(TM_THREADS), (size_t)dpad * 4 * 3, h->stream,
-                                   h->X.p, h->norm2.p, N, dpad, h->perm.p, d_tasks.p, seed, hp_level);
+                const int nvq = (dpad / 4 + WAVE - 1) / WAVE;   // float4 per lane per row
+                const unsigned wg = (unsigned)((A + 3) / 4);
+#define TMW_LAUNCH(NVV)                                                                                              \
+    hipLaunchKernelGGL(two_means_wave_kernel<NVV>, dim3(wg), dim3(256), 0, h->stream, h->X.p, h->norm2.p, N, dpad, \
+                       h->perm.p, d_tasks.p, A, seed, hp_level)
+                if (nvq <= 1) TMW_LAUNCH(1);
+                else if (nvq <= 2) TMW_LAUNCH(2);
+                else if (nvq <= 4) TMW_LAUNCH(4);
+                else if (nvq <= 8) TMW_LAUNCH(8);
+                else if (nvq <= 12) TMW_LAUNCH(12);
+                else   // rows too long for the register file: centroids in LDS, one workgroup per node
+                    hipLaunchKernelGGL(two_means_kernel, dim3((unsigned)A), dim3(TM_THREADS), (size_t)dpad * 4 * 3, h->stream,
+                                       h->X.p, h->norm2.p, N, dpad, h->perm.p, d_tasks.p, seed, hp_level);
+#undef TMW_LAUNCH
             }
             {
                 // launch order: chunks sorted by first row id, one contiguous run per XCD
@@ -517,7 +775,48 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 hipLaunchKernelGGL(sched_scatter_kernel, dim3(cb), dim3(256), 0, h->stream, d_tasks.p, n_chunks, d_info.p,
                                    d_cursor.p, d_sched.p);
             }
-            {
+            // shallow level, whole level pending: row-window form (rows reused across a tree group)
+            int max_per_tree = 0;
+            tree_first.assign((size_t)n_trees + 1, A);
+            for (int32_t a = A - 1; a >= 0; a--) tree_first[(size_t)tasks[(size_t)a].tree] = a;
+            for (int t = n_trees - 1; t >= 0; t--)
+                if (tree_first[(size_t)t] > tree_first[(size_t)t + 1]) tree_first[(size_t)t] = tree_first[(size_t)t + 1];
+            for (int t = 0; t < n_trees; t++)
+                max_per_tree = std::max(max_per_tree, tree_first[(size_t)t + 1] - tree_first[(size_t)t]);
+            const int nv = (dpad / 4 + WAVE - 1) / WAVE;
+            // measured on MI355X (C3): 5.3 / 6.1 / 7.9 ms at levels 0-2 against 5.0 ms for the chunk form --
+            // the dependent ds_bpermute reductions at one workgroup per CU cost more than the L2 reads
+            // they save -- so the row-window form stays off until its reductions are pipelined.
+            static const bool rw_enabled = getenv("MORNA_SPLIT_RW") != nullptr;
+            const bool use_rw = rw_enabled && attempt == 0 && max_per_tree >= 1 && max_per_tree <= RW_SLOTS / 2 &&
+                                nv <= 16 && rows * 2 >= (int64_t)n_trees * N;
+            if (use_rw) {
+                const int G = RW_SLOTS / (max_per_tree == 3 ? 4 : max_per_tree);
+                const int n_windows = (int)((N + RW_ROWS - 1) / RW_ROWS), n_groups = (n_trees + G - 1) / G;
+                if ((rc = row_task.alloc((size_t)n_trees * N)) || (rc = row_pos.alloc((size_t)n_trees * N)) ||
+                    (rc = d_tree_first.alloc((size_t)n_trees + 1))) { cleanup(); return rc; }
+                F_TRY(hipMemcpyAsync(d_tree_first.p, tree_first.data(), ((size_t)n_trees + 1) * 4, hipMemcpyHostToDevice, h->stream));
+                F_TRY(hipMemsetAsync(row_task.p, 0xFF, (size_t)n_trees * N * 4, h->stream));
+                hipLaunchKernelGGL(invert_kernel, dim3((unsigned)n_chunks), dim3(64), 0, h->stream, d_tasks.p, d_info.p, n_chunks,
+                                   h->perm.p, N, row_task.p, row_pos.p);
+                ScopedTimer tm(h, MORNA_T_SPLIT, 4 * (int64_t)D * (rows + A));
+                const unsigned grid = 8u * (unsigned)((n_windows + 7) / 8) * (unsigned)n_groups;
+                const size_t lds = (size_t)RW_SLOTS * dpad * 4;
+#define RW_LAUNCH(NVV)                                                                                                   \
+    do {                                                                                                                 \
+        F_TRY(hipFuncSetAttribute((const void *)split_rw_kernel<NVV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(split_rw_kernel<NVV>, dim3(grid), dim3(RW_THREADS), lds, h->stream, h->X.p, N, dpad, d_tasks.p,  \
+                           d_tree_first.p, n_trees, G, row_task.p, row_pos.p, seed, hp_level, side.p, d_ones.p, n_windows, \
+                           n_groups);                                                                                    \
+    } while (0)
+                if (nv <= 1) RW_LAUNCH(1);
+                else if (nv <= 2) RW_LAUNCH(2);
+                else if (nv <= 4) RW_LAUNCH(4);
+                else if (nv <= 8) RW_LAUNCH(8);
+                else if (nv <= 12) RW_LAUNCH(12);
+                else RW_LAUNCH(16);
+#undef RW_LAUNCH
+            } else {
                 // algorithmic bytes: 4*D*sum|node| + 4*D*#split nodes
                 ScopedTimer tm(h, MORNA_T_SPLIT, 4 * (int64_t)D * (rows + A));
                 const unsigned grid = 8u * (unsigned)((n_chunks + 7) / 8);
