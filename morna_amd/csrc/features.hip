@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void line_flags_kernel(const int64_t *__restri
 
 #define ACC_TILE 8192     // samples per tile: 64 KiB of fp64 accumulators in LDS
 #define ACC_LINES 256     // lines whose extents are staged per pass
+#define ACC_PF 8          // entries per thread prefetched from the next line
 
 __global__ __launch_bounds__(ACC_THREADS) void accumulate_kernel(
     const int32_t *__restrict__ col_off, const int32_t *__restrict__ col_lines, const double *__restrict__ sidf,
@@ -166,9 +167,28 @@ __global__ __launch_bounds__(ACC_THREADS) void accumulate_kernel(
             s_b[tid] = row_ptr[j]; s_e[tid] = row_ptr[j + 1]; s_w[tid] = sidf[j]; s_f[tid] = flags[j];
         }
         __syncthreads();
+        // the first ACC_PF * 256 entries of line i+1 are fetched into registers while line i is
+        // added, so the barrier between two lines does not expose the global-load latency
+        int32_t id_c[ACC_PF], cv_c[ACC_PF], id_n[ACC_PF], cv_n[ACC_PF];
+        auto fetch = [&](int i, int32_t(&idr)[ACC_PF], int32_t(&cvr)[ACC_PF]) {
+            const int64_t b = s_b[i], e = s_e[i];
+#pragma unroll
+            for (int m = 0; m < ACC_PF; m++) {
+                const int64_t t = b + tid + (int64_t)m * ACC_THREADS;
+                idr[m] = t < e ? ids[t] : -1;
+                cvr[m] = t < e ? cov[t] : 0;
+            }
+        };
+#pragma unroll
+        for (int m = 0; m < ACC_PF; m++) {
+            id_n[m] = -1;
+            cv_n[m] = 0;
+        }
+        fetch(0, id_c, cv_c);
         for (int i = 0; i < nb; i++) {
             const int64_t b = s_b[i], e = s_e[i];
             const double wgt = s_w[i];
+            if (i + 1 < nb) fetch(i + 1, id_n, cv_n);
             if (s_f[i]) {
                 // a sample repeats inside this line: keep the line's own order
                 if (tid == 0)
@@ -178,11 +198,21 @@ __global__ __launch_bounds__(ACC_THREADS) void accumulate_kernel(
                     }
             } else {
                 // every sample at most once: the lanes touch distinct cells of the tile
-                for (int64_t t = b + tid; t < e; t += ACC_THREADS) {
-                    const uint32_t off = (uint32_t)((int64_t)ids[t] - r_lo);
+#pragma unroll
+                for (int m = 0; m < ACC_PF; m++) {
+                    const uint32_t off = (uint32_t)((int64_t)id_c[m] - r_lo);   // -1 (no entry) is out of range
                     // tf_idf = cov * idf (one rounding), then += (one rounding): morna.py:384-388
+                    if (id_c[m] >= 0 && off < span) acc[off] = __dadd_rn(acc[off], __dmul_rn((double)cv_c[m], wgt));
+                }
+                for (int64_t t = b + tid + (int64_t)ACC_PF * ACC_THREADS; t < e; t += ACC_THREADS) {
+                    const uint32_t off = (uint32_t)((int64_t)ids[t] - r_lo);
                     if (off < span) acc[off] = __dadd_rn(acc[off], __dmul_rn((double)cov[t], wgt));
                 }
+            }
+#pragma unroll
+            for (int m = 0; m < ACC_PF; m++) {
+                id_c[m] = id_n[m];
+                cv_c[m] = cv_n[m];
             }
             __syncthreads();   // the next line of this column may touch the same cells
         }
