@@ -98,7 +98,7 @@ int morna_index_create(int32_t dim, int32_t device, morna_index **out)
         return MORNA_E_INVALID;
     }
     h->dim = dim;
-    h->dpad = (dim + 31) / 32 * 32;
+    h->dpad = (dim + 255) / 256 * 256;   // whole 1-KiB wave loads: every lane active in every k-step
     h->K = dim + 2;
     h->device = device;
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);

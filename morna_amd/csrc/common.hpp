@@ -82,7 +82,7 @@ struct PendingEv {
 
 struct morna_index {
     int32_t dim = 0;     // D (f in annoy)
-    int32_t dpad = 0;    // row stride in floats: D rounded up to 32 (128-byte rows)
+    int32_t dpad = 0;    // row stride in floats: D rounded up to 256 (one 1-KiB load per wave and k-step)
     int32_t device = 0;
     int32_t K = 0;       // leaf capacity D + 2
     hipStream_t stream = nullptr;

@@ -198,15 +198,13 @@ __device__ inline float reg_dot(const float4 (&a)[NV], const float4 (&b)[NV])
     return wave_dot_finish(s0, s1, s2, s3);
 }
 
+// rows are padded to NV * 256 floats exactly (dpad is a multiple of 256): no lane is ever idle
 template <int NV>
 __device__ inline void reg_load_row(const float *row, int nvec, int lane, float4 (&x)[NV])
 {
     const float4 *xp = (const float4 *)row;
 #pragma unroll
-    for (int k = 0; k < NV; k++) {
-        const int i = lane + k * WAVE;
-        x[k] = i < nvec ? xp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int k = 0; k < NV; k++) x[k] = xp[lane + k * WAVE];
 }
 
 template <int NV>
@@ -290,10 +288,7 @@ __global__ __launch_bounds__(256) void two_means_wave_kernel(const float *__rest
     reg_normalize<NV>(p);
     float4 *out = (float4 *)(hp + (int64_t)t.slot * dpad);
 #pragma unroll
-    for (int kk = 0; kk < NV; kk++) {
-        const int idx = lane + kk * WAVE;
-        if (idx < nvec) out[idx] = p[kk];
-    }
+    for (int kk = 0; kk < NV; kk++) out[lane + kk * WAVE] = p[kk];
 }
 
 // ---------------------------------------------------------------- split kernel
@@ -481,10 +476,7 @@ __global__ __launch_bounds__(RW_THREADS) void split_rw_kernel(
             const int64_t row = row_base + rr;
             const float4 *xp = (const float4 *)(X + row * dpad);
 #pragma unroll
-            for (int k = 0; k < NV; k++) {
-                const int i = lane + k * WAVE;
-                xr[k] = i < nvec ? xp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int k = 0; k < NV; k++) xr[k] = xp[lane + k * WAVE];   // dpad == NV * 256: no idle lane
             ma = -1;
             mp = 0;
             if (lane < ng) {
@@ -500,14 +492,11 @@ __global__ __launch_bounds__(RW_THREADS) void split_rw_kernel(
                 const int s = a - a0;
                 const float4 *hv = hs + s * nvec;
                 float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+                float4 h4[NV];
 #pragma unroll
-                for (int k = 0; k < NV; k++) {
-                    const int i = lane + k * WAVE;
-                    if (i < nvec) {
-                        const float4 h4 = hv[i];
-                        FMA4(c, xr[k], h4);
-                    }
-                }
+                for (int k = 0; k < NV; k++) h4[k] = hv[lane + k * WAVE];
+#pragma unroll
+                for (int k = 0; k < NV; k++) FMA4(c, xr[k], h4[k]);
                 const float d = wave_dot_finish(c0, c1, c2, c3);
                 const int sd = d != 0.f ? (d > 0.f) : pos_flip(s_seed[s], (uint32_t)p);
                 if (lane == 0) {
@@ -754,12 +743,14 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
 #define TMW_LAUNCH(NVV)                                                                                              \
     hipLaunchKernelGGL(two_means_wave_kernel<NVV>, dim3(wg), dim3(256), 0, h->stream, h->X.p, h->norm2.p, N, dpad, \
                        h->perm.p, d_tasks.p, A, seed, hp_level)
-                if (nvq <= 1) TMW_LAUNCH(1);
-                else if (nvq <= 2) TMW_LAUNCH(2);
-                else if (nvq <= 4) TMW_LAUNCH(4);
-                else if (nvq <= 8) TMW_LAUNCH(8);
-                else if (nvq <= 12) TMW_LAUNCH(12);
-                else   // rows too long for the register file: centroids in LDS, one workgroup per node
+                if (nvq == 1) TMW_LAUNCH(1);
+                else if (nvq == 2) TMW_LAUNCH(2);
+                else if (nvq == 3) TMW_LAUNCH(3);
+                else if (nvq == 4) TMW_LAUNCH(4);
+                else if (nvq == 6) TMW_LAUNCH(6);
+                else if (nvq == 8) TMW_LAUNCH(8);
+                else if (nvq == 12) TMW_LAUNCH(12);
+                else   // other row lengths (or too long for the register file): centroids in LDS, one workgroup per node
                     hipLaunchKernelGGL(two_means_kernel, dim3((unsigned)A), dim3(TM_THREADS), (size_t)dpad * 4 * 3, h->stream,
                                        h->X.p, h->norm2.p, N, dpad, h->perm.p, d_tasks.p, seed, hp_level);
 #undef TMW_LAUNCH
@@ -788,8 +779,9 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             // the dependent ds_bpermute reductions at one workgroup per CU cost more than the L2 reads
             // they save -- so the row-window form stays off until its reductions are pipelined.
             static const bool rw_enabled = getenv("MORNA_SPLIT_RW") != nullptr;
+            const bool nv_ok = nv == 1 || nv == 2 || nv == 3 || nv == 4 || nv == 6 || nv == 8 || nv == 12;
             const bool use_rw = rw_enabled && attempt == 0 && max_per_tree >= 1 && max_per_tree <= RW_SLOTS / 2 &&
-                                nv <= 16 && rows * 2 >= (int64_t)n_trees * N;
+                                nv_ok && rows * 2 >= (int64_t)n_trees * N;
             if (use_rw) {
                 const int G = RW_SLOTS / (max_per_tree == 3 ? 4 : max_per_tree);
                 const int n_windows = (int)((N + RW_ROWS - 1) / RW_ROWS), n_groups = (n_trees + G - 1) / G;
@@ -809,12 +801,13 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                            d_tree_first.p, n_trees, G, row_task.p, row_pos.p, seed, hp_level, side.p, d_ones.p, n_windows, \
                            n_groups);                                                                                    \
     } while (0)
-                if (nv <= 1) RW_LAUNCH(1);
-                else if (nv <= 2) RW_LAUNCH(2);
-                else if (nv <= 4) RW_LAUNCH(4);
-                else if (nv <= 8) RW_LAUNCH(8);
-                else if (nv <= 12) RW_LAUNCH(12);
-                else RW_LAUNCH(16);
+                if (nv == 1) RW_LAUNCH(1);
+                else if (nv == 2) RW_LAUNCH(2);
+                else if (nv == 3) RW_LAUNCH(3);
+                else if (nv == 4) RW_LAUNCH(4);
+                else if (nv == 6) RW_LAUNCH(6);
+                else if (nv == 8) RW_LAUNCH(8);
+                else RW_LAUNCH(12);
 #undef RW_LAUNCH
             } else {
                 // algorithmic bytes: 4*D*sum|node| + 4*D*#split nodes
