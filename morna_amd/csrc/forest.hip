@@ -414,7 +414,7 @@ __global__ __launch_bounds__(SP_THREADS) void split_kernel(const float *__restri
 // the hyperplane of its node in every tree of the group.  L2 -> CU traffic per
 // (row, tree) drops from one row to 1/G row; same wave_dot order, same results.
 
-#define RW_THREADS 512
+#define RW_THREADS 512    // 1024 caps the kernel at 128 VGPRs and spills the two row buffers
 #define RW_WAVES (RW_THREADS / WAVE)
 #define RW_ROWS 64
 #define RW_SLOTS 8
@@ -486,9 +486,9 @@ __global__ __launch_bounds__(RW_THREADS) void split_rw_kernel(
         };
         auto process = [&](const float4(&xr)[NV], int ma, int mp) {
             for (int gi = 0; gi < ng; gi++) {
-                const int a = __shfl(ma, gi, WAVE);   // same for the whole wave
+                const int a = __builtin_amdgcn_readlane(ma, gi);   // v_readlane: gi is wave-uniform
                 if (a < 0) continue;
-                const int p = __shfl(mp, gi, WAVE);
+                const int p = __builtin_amdgcn_readlane(mp, gi);
                 const int s = a - a0;
                 const float4 *hv = hs + s * nvec;
                 float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
@@ -775,12 +775,12 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             for (int t = 0; t < n_trees; t++)
                 max_per_tree = std::max(max_per_tree, tree_first[(size_t)t + 1] - tree_first[(size_t)t]);
             const int nv = (dpad / 4 + WAVE - 1) / WAVE;
-            // measured on MI355X (C3): 5.3 / 6.1 / 7.9 ms at levels 0-2 against 5.0 ms for the chunk form --
-            // the dependent ds_bpermute reductions at one workgroup per CU cost more than the L2 reads
-            // they save -- so the row-window form stays off until its reductions are pipelined.
-            static const bool rw_enabled = getenv("MORNA_SPLIT_RW") != nullptr;
+            // measured on MI355X (C3, 1e7 rows per level): 3.4 / 4.3 / 5.9 ms with 1 / 2 / 4 nodes per tree
+            // against 4.6 ms for the chunk form, so it is used while a tree has at most 2 split nodes
+            // (MORNA_SPLIT_RW=0 turns it off, =4 extends it to 4 nodes per tree)
+            static const int rw_max = getenv("MORNA_SPLIT_RW") ? atoi(getenv("MORNA_SPLIT_RW")) : 2;
             const bool nv_ok = nv == 1 || nv == 2 || nv == 3 || nv == 4 || nv == 6 || nv == 8 || nv == 12;
-            const bool use_rw = rw_enabled && attempt == 0 && max_per_tree >= 1 && max_per_tree <= RW_SLOTS / 2 &&
+            const bool use_rw = attempt == 0 && max_per_tree >= 1 && max_per_tree <= std::min(rw_max, RW_SLOTS / 2) &&
                                 nv_ok && rows * 2 >= (int64_t)n_trees * N;
             if (use_rw) {
                 const int G = RW_SLOTS / (max_per_tree == 3 ? 4 : max_per_tree);
