@@ -235,6 +235,7 @@ int morna_unstage_junctions(morna_index *h)
     CHECK_H(h);
     h->s_keys.release(); h->s_key_off.release(); h->s_row_ptr.release();
     h->s_ids.release(); h->s_cov.release(); h->s_idf.release();
+    for (int i = 0; i < 8; i++) h->scratch[i].release();   // feature-build scratch (fp64 column image ...)
     h->staged = false;
     h->J = h->nnz = h->key_bytes_n = 0;
     return MORNA_OK;

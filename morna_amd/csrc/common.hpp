@@ -61,6 +61,20 @@ struct DevBuf {
     }
 };
 
+// typed view of one persistent scratch slot (same .p / .alloc surface as DevBuf)
+template <typename T>
+struct ScratchRef {
+    DevBuf<uint8_t> &b;
+    T *p = nullptr;
+    explicit ScratchRef(DevBuf<uint8_t> &buf) : b(buf), p((T *)buf.p) {}
+    int alloc(size_t count)
+    {
+        int rc = b.alloc(count * sizeof(T));
+        p = (T *)b.p;
+        return rc;
+    }
+};
+
 // A node of the forest as the host driver tracks it (perm segment of one tree).
 struct Seg {
     int32_t tree, level, start, count, node;
@@ -121,6 +135,9 @@ struct morna_index {
 
     // query workspace (grown on demand)
     morna::DevBuf<uint8_t> ws;
+    // build scratch kept between calls (feature and forest builds reuse it instead of
+    // hipMalloc / hipFree on every call); slots are named in features.hip / forest.hip
+    morna::DevBuf<uint8_t> scratch[24];
     // [0] rows read by query kernels (hyperplane dots + candidates + 1 per query)
     morna::DevBuf<unsigned long long> d_stat;
 

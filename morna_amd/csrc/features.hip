@@ -337,9 +337,10 @@ int build_features(morna_index *h, int64_t n_items)
         set_error("build_features: %lld junction lines exceed the 2^31 limit", (long long)J);
         return MORNA_E_INVALID;
     }
-    DevBuf<int32_t> col, col_count, col_off, col_lines;
-    DevBuf<double> sidf, colacc;
-    DevBuf<uint8_t> flags;
+    // scratch lives in the handle (released by morna_unstage_junctions): a rebuild does no hipMalloc
+    ScratchRef<int32_t> col(h->scratch[0]), col_count(h->scratch[1]), col_off(h->scratch[2]), col_lines(h->scratch[3]);
+    ScratchRef<double> sidf(h->scratch[4]), colacc(h->scratch[5]);
+    ScratchRef<uint8_t> flags(h->scratch[6]);
     // algorithmic bytes of this pass: 8*nnz + keys + 8*J + 4*N*D
     const int64_t alg_bytes = 8 * h->nnz + h->key_bytes_n + 8 * J + 4 * n_items * (int64_t)D;
     MORNA_TRY(col.alloc((size_t)J));
@@ -383,7 +384,7 @@ int build_features(morna_index *h, int64_t n_items)
         h->built = false;
         MORNA_TRY(compute_norms(h));
     }
-    HIP_TRY(hipStreamSynchronize(h->stream));   // scratch buffers are freed on return
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return MORNA_OK;
 }
 

@@ -646,19 +646,20 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
     h->stats.n_trees = n_trees;
 
     MORNA_TRY(h->perm.alloc((size_t)n_trees * N));
-    DevBuf<int32_t> tmp, d_ones;
-    DevBuf<uint8_t> side;
-    DevBuf<SplitTask> d_tasks;
+    // scratch lives in the handle: a rebuild (or the next level) reuses it without hipMalloc
+    ScratchRef<int32_t> tmp(h->scratch[8]), d_ones(h->scratch[9]);
+    ScratchRef<uint8_t> side(h->scratch[10]);
+    ScratchRef<SplitTask> d_tasks(h->scratch[11]);
     MORNA_TRY(tmp.alloc((size_t)n_trees * N));
     MORNA_TRY(side.alloc((size_t)n_trees * N));
     // launch-order scratch of the split kernel: buckets of 32 row ids
-    DevBuf<int32_t> d_hist, d_cursor;
-    DevBuf<int2> d_info, d_sched;
+    ScratchRef<int32_t> d_hist(h->scratch[12]), d_cursor(h->scratch[13]);
+    ScratchRef<int2> d_info(h->scratch[14]), d_sched(h->scratch[15]);
     const int32_t n_buckets = (int32_t)std::min<int64_t>(SCHED_MAX_BUCKETS, std::max<int64_t>(1, (N + 31) / 32));
     MORNA_TRY(d_hist.alloc((size_t)n_buckets));
     MORNA_TRY(d_cursor.alloc((size_t)n_buckets));
     // row-window form of the shallow levels: inverse permutation per tree
-    DevBuf<int32_t> row_task, row_pos, d_tree_first;
+    ScratchRef<int32_t> row_task(h->scratch[16]), row_pos(h->scratch[17]), d_tree_first(h->scratch[18]);
     std::vector<int32_t> tree_first;
     {
         const int64_t total = (int64_t)n_trees * N;
@@ -676,19 +677,15 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
         ntree.push_back(t);
         nhp.push_back(-1);
     }
-    // hyperplanes are produced level by level into growing storage
-    std::vector<float *> level_hp;          // device buffers, one per level
-    std::vector<int32_t> level_hp_count;
+    // hyperplanes are produced level by level straight into h->hp, which grows geometrically
+    // (and is kept across rebuilds); slot = n_split_total + index within the level
     int64_t n_split_total = 0;
     int rc = MORNA_OK;
     std::vector<SplitTask> tasks, pend;
     std::vector<int32_t> h_ones;
     int32_t level = 0;
 
-    auto cleanup = [&]() {
-        for (float *p : level_hp) (void)hipFree(p);
-        level_hp.clear();
-    };
+    auto cleanup = [&]() {};
 #define F_TRY(e)                                                    \
     do {                                                            \
         hipError_t _e = (e);                                        \
@@ -707,10 +704,21 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
         h->stats.max_depth = std::max<int64_t>(h->stats.max_depth, level);
         if (split_idx.empty()) break;
         const int32_t S = (int32_t)split_idx.size();
-        float *hp_level = nullptr;
-        F_TRY(hipMalloc((void **)&hp_level, (size_t)S * dpad * sizeof(float)));
-        level_hp.push_back(hp_level);
-        level_hp_count.push_back(S);
+        {
+            const size_t need = (size_t)(n_split_total + S) * dpad;
+            if (need > h->hp.n) {   // the stream is idle here (synchronised at the end of the previous level)
+                DevBuf<float> bigger;
+                if ((rc = bigger.alloc(std::max(need, h->hp.n * 2)))) return rc;
+                if (n_split_total > 0)
+                    F_TRY(hipMemcpy(bigger.p, h->hp.p, (size_t)n_split_total * dpad * 4, hipMemcpyDeviceToDevice));
+                h->hp.release();
+                h->hp.p = bigger.p;
+                h->hp.n = bigger.n;
+                bigger.p = nullptr;
+                bigger.n = 0;
+            }
+        }
+        float *hp_level = h->hp.p + (size_t)n_split_total * dpad;
 
         // final outcome per split node of this level
         std::vector<int32_t> final_ones((size_t)S, 0);
@@ -890,15 +898,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
     // consolidate hyperplanes and node tables in HBM
     h->n_split = n_split_total;
     h->n_nodes = (int64_t)ntree.size();
-    if ((rc = h->hp.alloc((size_t)std::max<int64_t>(n_split_total, 1) * dpad))) { cleanup(); return rc; }
-    {
-        int64_t off = 0;
-        for (size_t l = 0; l < level_hp.size(); l++) {
-            F_TRY(hipMemcpyAsync(h->hp.p + off * dpad, level_hp[l], (size_t)level_hp_count[l] * dpad * 4,
-                                 hipMemcpyDeviceToDevice, h->stream));
-            off += level_hp_count[l];
-        }
-    }
+    if ((rc = h->hp.alloc((size_t)dpad))) return rc;   // never a null hyperplane table (N <= K: no split at all)
     if ((rc = h->node_rec.alloc(rec.size())) || (rc = h->node_tree.alloc(ntree.size())) || (rc = h->node_hp.alloc(nhp.size()))) {
         cleanup();
         return rc;
