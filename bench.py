@@ -189,8 +189,9 @@ def main():
         if os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
-            if tj.get("config") == {"samples": N, "features": D, "trees": T} and "morna::split_kernel" in tj["kernels"]:
-                traffic = tj["kernels"]["morna::split_kernel"]["hbm_bytes_per_launch"]
+            ks = [v for k, v in tj["kernels"].items() if k.startswith(("morna::split_kernel", "morna::split_rw_kernel"))]
+            if tj.get("config") == {"samples": N, "features": D, "trees": T} and ks:
+                traffic = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in ks) / max(sum(v["calls"] for v in ks), 1)
                 traffic_src = "profiles/r01_c3_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
         total_samples = n_items * world * args.steps
         out = {
@@ -213,7 +214,8 @@ def main():
             "forest": {"n_nodes": st["n_nodes"], "n_split": st["n_split"], "max_depth": st["max_depth"],
                        "split_rows": st["split_rows"], "split_attempts": st["split_attempts"],
                        "fallback_nodes": st["fallback_nodes"]},
-            "roofline": {"kernel": "split_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "split_kernel (+ split_rw_kernel, its row-window form at the two shallowest levels)",
+                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "launches": sp["launches"] // max(args.steps, 1),
                          "alg_bytes_per_launch": sp["bytes"] // max(sp["launches"], 1),
