@@ -74,6 +74,26 @@ int morna_unstage_junctions(morna_index *h);
 int morna_hash_keys(morna_index *h, const uint8_t *key_bytes, const int64_t *key_off, int64_t J,
                     int32_t *hash_out, int32_t *col_out, int32_t *sign_out);
 
+/*
+ * Native host pre-pass of `morna index` (no GPU work): go_index's line loop,
+ * count_samples and the host half of add_junction                morna.py:841-861, 789-822, 357-382
+ * Reads a gzipped (or plain) intropolis file; sample_count <= 0 counts the distinct
+ * sample-id strings first, as go_index does without -s.  The result holds exactly the
+ * arrays morna_stage_junctions takes, plus the external sample id of every internal id
+ * and the final junction -> frequency table (what .map.mor / .freq.mor store).
+ */
+typedef struct morna_lines morna_lines;
+int morna_parse_intropolis(const char *path, int64_t sample_count, int64_t sample_threshold, morna_lines **out);
+/* counts[8] = kept lines, nnz, n_items, skipped, sample_count, key bytes, distinct keys, lines read */
+int morna_lines_counts(const morna_lines *L, int64_t *counts);
+/* borrowed pointers, valid until morna_lines_free; any may be NULL */
+int morna_lines_arrays(const morna_lines *L, const uint8_t **key_bytes, const int64_t **key_off,
+                       const int64_t **row_ptr, const int32_t **item_ids, const int32_t **cov, const double **idf,
+                       const int64_t **ext_ids);
+int morna_lines_freq_entry(const morna_lines *L, int64_t i, const char **key, int64_t *key_len, int64_t *freq);
+int morna_stage_lines(morna_index *h, const morna_lines *L);
+int morna_lines_free(morna_lines *L);
+
 /* AnnoyIndex.get_n_items()                                     morna.py:1174 */
 int64_t morna_get_n_items(const morna_index *h);
 /* AnnoyIndex.get_item_vector(i)                                morna.py:702 */

@@ -37,6 +37,12 @@ SIGNATURES = {
     "morna_build_features": (C.c_int, [_p, _i64]),
     "morna_unstage_junctions": (C.c_int, [_p]),
     "morna_hash_keys": (C.c_int, [_p, _p, _p, _i64, _p, _p, _p]),
+    "morna_parse_intropolis": (C.c_int, [C.c_char_p, _i64, _i64, C.POINTER(_p)]),
+    "morna_lines_counts": (C.c_int, [_p, _p]),
+    "morna_lines_arrays": (C.c_int, [_p] + [C.POINTER(_p)] * 7),
+    "morna_lines_freq_entry": (C.c_int, [_p, _i64, C.POINTER(C.c_char_p), C.POINTER(_i64), C.POINTER(_i64)]),
+    "morna_stage_lines": (C.c_int, [_p, _p]),
+    "morna_lines_free": (C.c_int, [_p]),
     "morna_get_n_items": (_i64, [_p]),
     "morna_get_item_vector": (C.c_int, [_p, _i32, _p]),
     "morna_get_item_vectors": (C.c_int, [_p, _p, _i64, _p]),

@@ -61,6 +61,9 @@ def build_parser():
                               help='accepted for compatibility; the per-sample junction database is out of scope')
     index_parser.add_argument('-v', '--verbose', action='store_const', const=True, default=False, help='be talkative')
     index_parser.add_argument('--device', type=int, default=0, help='HIP device ordinal')
+    index_parser.add_argument('--python-parse', action='store_const', const=True, default=False,
+                              help='tokenise the intropolis file with the Python loop of the reference '
+                                   'instead of the native pre-pass (same index either way)')
     add_search_parameters(search_parser)
     return parser
 
@@ -72,7 +75,8 @@ def main(argv=None, stdin=None, stdout=None):
     if args.subparser_name == 'index':
         from .index import go_index
         go_index(args.intropolis, args.basename, args.features, args.n_trees, args.sample_count,
-                 args.sample_threshold, args.buffer_size, args.verbose, None, device=args.device)
+                 args.sample_threshold, args.buffer_size, args.verbose, None, device=args.device,
+                 native=not args.python_parse)
         return 0
     if args.subparser_name != 'search':
         build_parser().print_help()

@@ -1,0 +1,287 @@
+// parse.hip -- native host-side pre-pass of `morna index` (no GPU work here).
+//
+// Counterpart of the reference's go_index line loop, count_samples and the host
+// half of MornaIndex.add_junction (commanderson/morna morna.py:841-861, 789-822,
+// 357-382): reads a (gzipped) intropolis file and produces exactly the CSR arrays
+// morna_stage_junctions() takes -- kept lines in file order, first-seen internal
+// ids, cumulative junction frequencies, idf = log(sample_count / freq) from libm.
+// The Python tokenising loop is the reference's real end-to-end cost (SURVEY.md
+// section 8f N1); this does the same work at I/O speed.
+#include <zlib.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "common.hpp"
+
+struct morna_lines {
+    std::vector<uint8_t> key_bytes;
+    std::vector<int64_t> key_off{0}, row_ptr{0};
+    std::vector<int32_t> item_ids, cov;
+    std::vector<double> idf;
+    std::vector<int64_t> ext_ids;                       // external sample id of each internal id
+    std::unordered_map<std::string, int64_t> freq;      // sample_frequencies (morna.py:365)
+    std::vector<std::string> freq_keys;                 // insertion order, for the accessor
+    std::vector<int64_t> freq_vals;
+    int64_t sample_count = 0, skipped = 0, lines_read = 0;
+};
+
+namespace {
+
+using morna::set_error;
+
+struct LineReader {
+    gzFile f = nullptr;
+    std::vector<char> buf;
+    bool open(const char *path)
+    {
+        f = gzopen(path, "rb");   // transparently reads plain text too
+        if (!f) return false;
+        gzbuffer(f, 1 << 20);
+        buf.resize(1 << 16);
+        return true;
+    }
+    // next line without its terminator; false at EOF
+    bool next(std::string &line)
+    {
+        line.clear();
+        for (;;) {
+            if (!gzgets(f, buf.data(), (int)buf.size())) return !line.empty();
+            size_t n = strlen(buf.data());
+            line.append(buf.data(), n);
+            if (n && buf[n - 1] == '\n') return true;
+            if (gzeof(f)) return !line.empty();
+        }
+    }
+    ~LineReader()
+    {
+        if (f) gzclose(f);
+    }
+};
+
+inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
+
+// Python's line.strip(): [b, e) without leading / trailing whitespace
+inline void strip(const std::string &s, size_t &b, size_t &e)
+{
+    b = 0;
+    e = s.size();
+    while (b < e && is_space(s[b])) b++;
+    while (e > b && is_space(s[e - 1])) e--;
+}
+
+// int(token) for the decimal tokens of an intropolis file (optional sign, surrounding blanks)
+inline bool parse_int(const char *p, const char *end, int64_t &out)
+{
+    while (p < end && is_space(*p)) p++;
+    while (end > p && is_space(end[-1])) end--;
+    if (p == end) return false;
+    bool neg = false;
+    if (*p == '+' || *p == '-') {
+        neg = *p == '-';
+        p++;
+    }
+    if (p == end) return false;
+    int64_t v = 0;
+    for (; p < end; p++) {
+        if (*p < '0' || *p > '9') return false;
+        v = v * 10 + (*p - '0');
+    }
+    out = neg ? -v : v;
+    return true;
+}
+
+// positions of the tab-separated tokens of s[b, e)
+inline void split_tabs(const std::string &s, size_t b, size_t e, std::vector<std::pair<size_t, size_t>> &tok)
+{
+    tok.clear();
+    size_t start = b;
+    for (size_t i = b; i <= e; i++)
+        if (i == e || s[i] == '\t') {
+            tok.emplace_back(start, i);
+            start = i + 1;
+        }
+}
+
+}  // namespace
+
+extern "C" {
+
+int morna_lines_free(morna_lines *L)
+{
+    delete L;
+    return MORNA_OK;
+}
+
+int morna_parse_intropolis(const char *path, int64_t sample_count, int64_t sample_threshold, morna_lines **out)
+{
+    if (!path || !out) {
+        set_error("parse_intropolis: null argument");
+        return MORNA_E_INVALID;
+    }
+    *out = nullptr;
+    std::string line;
+    std::vector<std::pair<size_t, size_t>> tok;
+    if (sample_count <= 0) {
+        // count_samples (morna.py:789-822): distinct sample-id STRINGS of column -2
+        LineReader r;
+        if (!r.open(path)) {
+            set_error("Unable to open %s", path);
+            return MORNA_E_IO;
+        }
+        std::unordered_set<std::string> seen;
+        while (r.next(line)) {
+            // the reference splits the raw line here (no strip): column -2 can never hold the newline
+            size_t e = line.size();
+            split_tabs(line, 0, e, tok);
+            if (tok.size() < 2) {
+                set_error("line %lld of %s has fewer than two tab-separated columns", (long long)seen.size(), path);
+                return MORNA_E_INVALID;
+            }
+            const auto &t = tok[tok.size() - 2];
+            size_t s = t.first;
+            for (size_t i = t.first; i <= t.second; i++)
+                if (i == t.second || line[i] == ',') {
+                    seen.emplace(line.data() + s, i - s);
+                    s = i + 1;
+                }
+        }
+        sample_count = (int64_t)seen.size();
+    }
+    LineReader r;
+    if (!r.open(path)) {
+        set_error("Unable to open %s", path);
+        return MORNA_E_IO;
+    }
+    morna_lines *L = new morna_lines();
+    L->sample_count = sample_count;
+    std::unordered_map<int64_t, int32_t> id_map;   // internal_id_map (morna.py:377-382)
+    std::vector<int64_t> samples, covs;
+    std::string key;
+    int64_t lineno = 0;
+    while (r.next(line)) {
+        lineno++;
+        size_t b, e;
+        strip(line, b, e);                                   // tokens = line.strip().split('\t')
+        split_tabs(line, b, e, tok);
+        if (tok.size() < 2) {
+            set_error("line %lld of %s has fewer than two tab-separated columns", (long long)lineno, path);
+            delete L;
+            return MORNA_E_INVALID;
+        }
+        key.clear();                                         // ' '.join(tokens[:3])
+        for (size_t i = 0; i < tok.size() && i < 3; i++) {
+            if (i) key.push_back(' ');
+            key.append(line, tok[i].first, tok[i].second - tok[i].first);
+        }
+        auto parse_list = [&](const std::pair<size_t, size_t> &t, std::vector<int64_t> &dst) {
+            dst.clear();
+            size_t s = t.first;
+            for (size_t i = t.first; i <= t.second; i++)
+                if (i == t.second || line[i] == ',') {
+                    int64_t v;
+                    if (!parse_int(line.data() + s, line.data() + i, v)) return false;
+                    dst.push_back(v);
+                    s = i + 1;
+                }
+            return true;
+        };
+        if (!parse_list(tok[tok.size() - 2], samples) || !parse_list(tok[tok.size() - 1], covs)) {
+            set_error("invalid literal for int() on line %lld of %s", (long long)lineno, path);
+            delete L;
+            return MORNA_E_INVALID;
+        }
+        if ((int64_t)samples.size() < sample_threshold) {    // morna.py:361-363
+            L->skipped++;
+            continue;
+        }
+        auto it = L->freq.find(key);
+        if (it == L->freq.end()) {
+            it = L->freq.emplace(key, 0).first;
+            L->freq_keys.push_back(key);
+        }
+        it->second += (int64_t)samples.size();               // morna.py:365
+        L->idf.push_back(log((double)sample_count / (double)it->second));   // morna.py:372-374
+        L->key_bytes.insert(L->key_bytes.end(), key.begin(), key.end());
+        L->key_off.push_back((int64_t)L->key_bytes.size());
+        const size_t n = samples.size() < covs.size() ? samples.size() : covs.size();   // zip() truncates
+        for (size_t i = 0; i < n; i++) {
+            auto f = id_map.find(samples[i]);
+            int32_t id;
+            if (f == id_map.end()) {
+                id = (int32_t)L->ext_ids.size();
+                id_map.emplace(samples[i], id);
+                L->ext_ids.push_back(samples[i]);
+            } else {
+                id = f->second;
+            }
+            L->item_ids.push_back(id);
+            L->cov.push_back((int32_t)covs[i]);
+        }
+        L->row_ptr.push_back((int64_t)L->item_ids.size());
+    }
+    L->lines_read = lineno;
+    L->freq_vals.reserve(L->freq_keys.size());
+    for (const std::string &k : L->freq_keys) L->freq_vals.push_back(L->freq[k]);
+    *out = L;
+    return MORNA_OK;
+}
+
+// counts[8] = {kept lines, nnz, n_items, skipped, sample_count, key bytes, distinct keys, lines read}
+int morna_lines_counts(const morna_lines *L, int64_t *counts)
+{
+    if (!L || !counts) return MORNA_E_INVALID;
+    counts[0] = (int64_t)L->idf.size();
+    counts[1] = (int64_t)L->item_ids.size();
+    counts[2] = (int64_t)L->ext_ids.size();
+    counts[3] = L->skipped;
+    counts[4] = L->sample_count;
+    counts[5] = (int64_t)L->key_bytes.size();
+    counts[6] = (int64_t)L->freq_keys.size();
+    counts[7] = L->lines_read;
+    return MORNA_OK;
+}
+
+// borrowed pointers, valid until morna_lines_free
+int morna_lines_arrays(const morna_lines *L, const uint8_t **key_bytes, const int64_t **key_off,
+                       const int64_t **row_ptr, const int32_t **item_ids, const int32_t **cov, const double **idf,
+                       const int64_t **ext_ids)
+{
+    if (!L) return MORNA_E_INVALID;
+    if (key_bytes) *key_bytes = L->key_bytes.data();
+    if (key_off) *key_off = L->key_off.data();
+    if (row_ptr) *row_ptr = L->row_ptr.data();
+    if (item_ids) *item_ids = L->item_ids.data();
+    if (cov) *cov = L->cov.data();
+    if (idf) *idf = L->idf.data();
+    if (ext_ids) *ext_ids = L->ext_ids.data();
+    return MORNA_OK;
+}
+
+// i-th distinct junction key (first-seen order) and its final cumulative frequency
+int morna_lines_freq_entry(const morna_lines *L, int64_t i, const char **key, int64_t *key_len, int64_t *freq)
+{
+    if (!L || i < 0 || i >= (int64_t)L->freq_keys.size()) return MORNA_E_RANGE;
+    *key = L->freq_keys[(size_t)i].data();
+    *key_len = (int64_t)L->freq_keys[(size_t)i].size();
+    *freq = L->freq_vals[(size_t)i];
+    return MORNA_OK;
+}
+
+int morna_stage_lines(morna_index *h, const morna_lines *L)
+{
+    if (!h || !L) {
+        set_error("stage_lines: null argument");
+        return MORNA_E_INVALID;
+    }
+    return morna_stage_junctions(h, L->key_bytes.data(), L->key_off.data(), (int64_t)L->idf.size(), L->row_ptr.data(),
+                                 L->item_ids.data(), L->cov.data(), L->idf.data());
+}
+
+}  // extern "C"

@@ -145,9 +145,94 @@ def tokenize_line(line):
             [int(c) for c in tokens[-1].split(',')])
 
 
+class ParsedLines(object):
+    """Result of the native pre-pass (morna_parse_intropolis): the kept junction
+    lines of an intropolis file as the arrays the C ABI stages, owned by the library."""
+
+    def __init__(self, path, sample_count=None, sample_threshold=100):
+        import ctypes as C
+        from ._lib import check, lib
+        self._p = C.c_void_p()
+        check(lib().morna_parse_intropolis(str(path).encode(), int(sample_count or 0), int(sample_threshold),
+                                           C.byref(self._p)))
+        counts = np.zeros(8, np.int64)
+        check(lib().morna_lines_counts(self._p, counts.ctypes.data_as(C.c_void_p)))
+        (self.n_lines, self.nnz, self.n_items, self.skipped, self.sample_count, self.key_bytes_n,
+         self.n_keys, self.lines_read) = [int(x) for x in counts]
+
+    def __del__(self):
+        p = getattr(self, "_p", None)
+        if p is not None and p.value:
+            from ._lib import lib
+            lib().morna_lines_free(p)
+            self._p = None
+
+    def arrays(self):
+        """numpy views of the library-owned arrays (valid while this object lives)."""
+        import ctypes as C
+        from ._lib import check, lib
+        ptrs = [C.c_void_p() for _ in range(7)]
+        check(lib().morna_lines_arrays(self._p, *[C.byref(p) for p in ptrs]))
+
+        def view(p, ctype, n):
+            if n == 0 or not p.value:
+                return np.zeros(0, dtype=np.dtype(ctype))
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(ctype)), shape=(n,))
+        return dict(key_bytes=view(ptrs[0], C.c_uint8, self.key_bytes_n),
+                    key_off=view(ptrs[1], C.c_int64, self.n_lines + 1),
+                    row_ptr=view(ptrs[2], C.c_int64, self.n_lines + 1),
+                    ids=view(ptrs[3], C.c_int32, self.nnz), cov=view(ptrs[4], C.c_int32, self.nnz),
+                    idf=view(ptrs[5], C.c_double, self.n_lines), ext_ids=view(ptrs[6], C.c_int64, self.n_items))
+
+    def frequencies(self):
+        """junction -> cumulative sample frequency (MornaIndex.sample_frequencies)."""
+        import ctypes as C
+        from ._lib import check, lib
+        out = {}
+        key, klen, freq = C.c_char_p(), C.c_int64(), C.c_int64()
+        for i in range(self.n_keys):
+            check(lib().morna_lines_freq_entry(self._p, i, C.byref(key), C.byref(klen), C.byref(freq)))
+            out[C.string_at(key, klen.value).decode("ascii")] = int(freq.value)
+        return out
+
+    def stage(self, index):
+        from ._lib import check, lib
+        check(lib().morna_stage_lines(index._h, self._p))
+
+
+def go_index_native(intropolis, basename, features, n_trees, sample_count, sample_threshold, buffer_size, verbose,
+                    metafile, device=0, save=True, seed=0):
+    """go_index with the tokenising loop done by the library (morna_parse_intropolis)
+    instead of the Python interpreter; same index, same files."""
+    parsed = ParsedLines(intropolis, sample_count, sample_threshold)
+    if verbose:
+        print('\nThere are {} samples.'.format(parsed.sample_count))
+    morna_index = MornaIndex(parsed.sample_count, basename, dim=features, sample_threshold=sample_threshold,
+                             metafile=metafile, buffer_size=buffer_size, device=device)
+    morna_index.junc_id = parsed.lines_read - 1
+    morna_index.skipped = parsed.skipped
+    morna_index.new_internal_id = parsed.n_items
+    ext = parsed.arrays()["ext_ids"]
+    morna_index.internal_id_map = {int(s): i for i, s in enumerate(ext.tolist())}
+    morna_index.sample_frequencies = defaultdict(int, parsed.frequencies())
+    if parsed.n_items == 0:
+        raise ValueError("No internal ids were assigned, indicating that no samples were added to the index. "
+                         "Likely caused when no junctions pass the sample threshold.")
+    parsed.stage(morna_index)
+    morna_index.build_features(parsed.n_items)
+    morna_index.unstage_junctions()
+    AnnoyIndex.build(morna_index, n_trees, seed=seed)
+    if save:
+        morna_index.save(basename)
+    return morna_index
+
+
 def go_index(intropolis, basename, features, n_trees, sample_count, sample_threshold, buffer_size, verbose,
-             metafile, device=0, save=True, seed=0):
+             metafile, device=0, save=True, seed=0, native=False):
     """`morna index` (morna.py:824-865): gzipped intropolis file -> index files."""
+    if native:
+        return go_index_native(intropolis, basename, features, n_trees, sample_count, sample_threshold, buffer_size,
+                               verbose, metafile, device=device, save=save, seed=seed)
     if not sample_count:
         with gzip.open(intropolis, "rt") as introp_file_handle:
             sample_count = count_samples(introp_file_handle, verbose)

@@ -48,6 +48,30 @@ def test_go_index_then_search_member(tmp_path, embedded, embedded_mats, name):
         s.search_member_n(424242, 10, 100)
 
 
+def test_native_prepass_builds_the_same_index(tmp_path):
+    """go_index with the library's tokenising pre-pass == go_index with the Python loop."""
+    import pickle
+    from conftest import GOLDEN
+    from morna_amd.index import go_index
+    src = str(tmp_path / "tiny.tsv.gz")
+    with open(os.path.join(GOLDEN, "tiny_intropolis.tsv")) as fh:
+        _write_gz(src, fh.readlines())
+    a = go_index(src, str(tmp_path / "py"), 128, 4, None, 100, 1024, False, None, native=False)
+    b = go_index(src, str(tmp_path / "nat"), 128, 4, None, 100, 1024, False, None, native=True)
+    assert a.sample_count == b.sample_count == 6850
+    assert a.get_items().tobytes() == b.get_items().tobytes()
+    assert a.internal_id_map == b.internal_id_map and dict(a.sample_frequencies) == dict(b.sample_frequencies)
+    items = np.arange(64, dtype=np.int32)
+    ra, rb = a.get_nns_by_item_batch(items, 10, 100), b.get_nns_by_item_batch(items, 10, 100)
+    assert ra[0].tolist() == rb[0].tolist() and ra[1].tobytes() == rb[1].tobytes()
+    for ext in (".stats.mor", ".freq.mor", ".map.mor"):
+        with open(str(tmp_path / "py") + ext, "rb") as f1, open(str(tmp_path / "nat") + ext, "rb") as f2:
+            if ext == ".stats.mor":
+                assert f1.read() == f2.read()
+            else:
+                assert pickle.load(f1) == pickle.load(f2)
+
+
 def test_cli_index_and_stream_search(tmp_path, embedded):
     from morna_amd import cli
     from oracle import morna_ref

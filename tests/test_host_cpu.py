@@ -97,3 +97,59 @@ def test_cli_parser_defaults_match_reference():
         ("morna", 3000, 200, None, 100, 1024)                         # morna.py:970-1021
     s = p.parse_args(["search", "-x", "idx"])
     assert (s.search_k, s.format, s.distances, s.query_id, s.exact, s.results) == (100, "sam", False, None, False, 20)
+
+
+# ---- native pre-pass (morna_parse_intropolis): no GPU involved -------------------------------
+
+def _write(path, lines, gz):
+    import gzip
+    if gz:
+        with gzip.open(path, "wt") as fh:
+            fh.write("".join(lines))
+    else:
+        with open(path, "w") as fh:
+            fh.write("".join(lines))
+
+
+@pytest.mark.parametrize("name", ["simple", "lossy", "lose_sample"])
+@pytest.mark.parametrize("gz", [True, False])
+def test_native_parser_equals_python_prepass(tmp_path, embedded, name, gz):
+    spec = embedded["expected"][name]
+    lines = embedded[spec["input"]]
+    path = str(tmp_path / ("j.tsv.gz" if gz else "j.tsv"))
+    _write(path, lines, gz)
+    keys, rp, s, c = _tok(lines)
+    want = mindex.prepare_csr(keys, rp, s, c, spec["sample_count"], spec["sample_threshold"])
+    for sc in (spec["sample_count"], None):                     # given with -s, or counted (two passes)
+        got = mindex.ParsedLines(path, sc, spec["sample_threshold"])
+        assert got.sample_count == 10 and got.n_items == spec["n_items"] and got.skipped == want["skipped"]
+        assert got.lines_read == len(lines)
+        a = got.arrays()
+        for k in ("key_bytes", "key_off", "row_ptr", "ids", "cov", "ext_ids"):
+            assert a[k].tolist() == np.asarray(want[k]).tolist(), k
+        assert a["idf"].tobytes() == want["idf"].tobytes()       # libm log on both sides: bit-identical
+        assert got.frequencies() == want["freq"]
+
+
+def test_native_parser_tiny_intropolis_and_errors(tmp_path):
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "tiny_intropolis_D128.npz"))
+    got = mindex.ParsedLines(os.path.join(GOLDEN, "tiny_intropolis.tsv"), None, 100)
+    assert got.sample_count == 6850 == int(g["sample_count"])   # counted: distinct sample-id strings
+    assert got.arrays()["ext_ids"].tolist() == g["ext_ids"].tolist()
+    assert got.n_lines == 3 and got.nnz == 2040 + 6210 + 1664
+    # duplicate keys accumulate frequency; zip() truncation; whitespace stripping
+    p = str(tmp_path / "d.tsv")
+    _write(p, ["chr1\t1\t2\t+\tGT\tAG\t7,9\t1,1\n", "  chr1\t1\t2\t-\tGT\tAG\t9,3,7\t5,6\n", "chr2\t5\t6\tx\t4\t1\n"], False)
+    got = mindex.ParsedLines(p, 20, 1)
+    a = got.arrays()
+    from math import log
+    assert a["idf"].tolist() == [log(20.0 / 2), log(20.0 / 5), log(20.0 / 1)]
+    assert a["ids"].tolist() == [0, 1, 1, 2, 3] and a["cov"].tolist() == [1, 1, 5, 6, 1]
+    assert got.frequencies() == {"chr1 1 2": 5, "chr2 5 6": 1}
+    with pytest.raises(IOError):
+        mindex.ParsedLines(str(tmp_path / "missing.gz"), 5, 1)
+    _write(p, ["chr1\t1\t2\t+\tGT\tAG\t7,x\t1,1\n"], False)
+    with pytest.raises(ValueError):
+        mindex.ParsedLines(p, 5, 1)
