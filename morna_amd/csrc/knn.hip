@@ -454,6 +454,105 @@ __global__ void exact_prep_kernel(const double *__restrict__ Qd, int64_t nq, int
     if (lane == 0) qn2[q] = s;
 }
 
+// ---- batched scan on the matrix cores ---------------------------------------------
+// Many queries against all rows is a dense contraction C[q][r] = sum_d Q[q][d] X[r][d]
+// (2*Q*N*D flop over 4*D*(Q+N) bytes per tile pass): the one GEMM-shaped piece of the
+// path, so it runs on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate).
+// 128 queries x 128 rows per workgroup, K stepped by 32 through LDS, each of the 4 waves
+// owns a 64 x 64 quadrant as 2 x 2 MFMA tiles.  The result only SELECTS candidates; the
+// returned distances are recomputed in the reference's fp64 order by exact_rerank_kernel.
+#define MM_TILE 128
+#define MM_BK 32
+#define MM_LD (MM_BK + 4)   // padded LDS row (floats); 144-byte rows keep float4 accesses aligned
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void exact_scan_mfma_kernel(const float *__restrict__ X, const float *__restrict__ norm2,
+                                                              int64_t n_items, int32_t dpad,
+                                                              const float *__restrict__ Qf, const float *__restrict__ qn2,
+                                                              int64_t nq, float *__restrict__ approx)
+{
+    __shared__ __attribute__((aligned(16))) float As[MM_TILE * MM_LD];   // queries  [128][36]
+    __shared__ __attribute__((aligned(16))) float Bs[MM_TILE * MM_LD];   // rows     [128][36]
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int wm = w >> 1, wn = w & 1;                 // the wave's 64 x 64 quadrant
+    const int64_t r0 = (int64_t)blockIdx.x * MM_TILE, q0 = (int64_t)blockIdx.y * MM_TILE;
+
+    // global -> register staging: 4 float4 per operand per thread (row = idx / 8, 16-byte column = idx % 8)
+    float4 ga[4], gb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int idx = tid + it * 256, row = idx >> 3, c4 = idx & 7;
+            const int64_t q = q0 + row, r = r0 + row;
+            ga[it] = q < nq ? *(const float4 *)(Qf + q * dpad + k0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            gb[it] = r < n_items ? *(const float4 *)(X + r * dpad + k0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int idx = tid + it * 256, row = idx >> 3, c4 = idx & 7;
+            *(float4 *)(As + row * MM_LD + c4 * 4) = ga[it];
+            *(float4 *)(Bs + row * MM_LD + c4 * 4) = gb[it];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    fetch(0);
+    stash();
+    __syncthreads();
+    const int lr = lane & 31, lh = lane >> 5;
+    for (int k0 = 0; k0 < dpad; k0 += MM_BK) {
+        const bool more = k0 + MM_BK < dpad;
+        if (more) fetch(k0 + MM_BK);                   // next K slab in flight under the MFMAs
+#pragma unroll
+        for (int blk = 0; blk < MM_BK / 8; blk++) {
+            // lane half h supplies k = 8*blk + 4*h + j to MFMA j: any k order is a valid sum here
+            float4 a4[2], b4[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                a4[t] = *(const float4 *)(As + (wm * 64 + t * 32 + lr) * MM_LD + blk * 8 + lh * 4);
+                b4[t] = *(const float4 *)(Bs + (wn * 64 + t * 32 + lr) * MM_LD + blk * 8 + lh * 4);
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                for (int tn = 0; tn < 2; tn++) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].x, b4[tn].x, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].y, b4[tn].y, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].z, b4[tn].z, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].w, b4[tn].w, acc[tm][tn], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (more) stash();
+        __syncthreads();
+    }
+    // epilogue: C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
+    // A (queries) indexes the rows of the tile, B (matrix rows) its columns: 32 lanes write 32 consecutive r.
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++) {
+            const int64_t r = r0 + wn * 64 + tn * 32 + lr;
+            const float rn = r < n_items ? norm2[r] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int64_t q = q0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (q < nq && r < n_items) {
+                    const double ppqq = (double)rn * (double)qn2[q];
+                    approx[q * n_items + r] = ppqq > 0.0 ? (float)(2.0 - 2.0 * (double)acc[tm][tn][e] / sqrt(ppqq)) : 2.0f;
+                }
+            }
+        }
+}
+
 template <int QT>
 static void launch_exact_scan(morna_index *h, int64_t N, int64_t nb, const float *Qf, const float *qn2, float *approx)
 {
@@ -505,10 +604,15 @@ int exact_search(morna_index *h, const double *q, int64_t nq, int32_t k, int32_t
         HIP_TRY(hipMemcpyAsync(Qd.p, q + q0 * D, (size_t)nb * D * 8, hipMemcpyHostToDevice, h->stream));
         {
             // one pass over the matrix per qt queries: 4*D*N bytes each
-            ScopedTimer tm(h, MORNA_T_EXACT, 4 * (int64_t)D * N * ((nb + qt - 1) / qt));
+            const int64_t q_per_pass = nb >= 32 ? MM_TILE : qt;
+            ScopedTimer tm(h, MORNA_T_EXACT, 4 * (int64_t)D * N * ((nb + q_per_pass - 1) / q_per_pass));
             hipLaunchKernelGGL(exact_prep_kernel, dim3((unsigned)((nb * WAVE + 255) / 256)), dim3(256), 0, h->stream,
                                Qd.p, nb, D, dpad, Qf.p, qn2.p);
-            if (qt == 8) launch_exact_scan<8>(h, N, nb, Qf.p, qn2.p, approx.p);
+            if (nb >= 32) {   // enough queries to fill MFMA tiles: dense contraction on the matrix cores
+                dim3 grid((unsigned)((N + MM_TILE - 1) / MM_TILE), (unsigned)((nb + MM_TILE - 1) / MM_TILE));
+                hipLaunchKernelGGL(exact_scan_mfma_kernel, grid, dim3(256), 0, h->stream, h->X.p, h->norm2.p, N, dpad, Qf.p,
+                                   qn2.p, nb, approx.p);
+            } else if (qt == 8) launch_exact_scan<8>(h, N, nb, Qf.p, qn2.p, approx.p);
             else if (qt == 4) launch_exact_scan<4>(h, N, nb, Qf.p, qn2.p, approx.p);
             else if (qt == 2) launch_exact_scan<2>(h, N, nb, Qf.p, qn2.p, approx.p);
             else launch_exact_scan<1>(h, N, nb, Qf.p, qn2.p, approx.p);
