@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--cpu-trees", type=int, default=2)
     ap.add_argument("--cpu-queries", type=int, default=50)
     ap.add_argument("--verify", action="store_true", help="check results against the exact search")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend; nccl (= RCCL) is the product path, gloo only rehearses "
+                         "--gpus N on a box with fewer GPUs")
     return ap.parse_args()
 
 
@@ -111,10 +114,17 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if args.backend == "gloo":
+        # rehearsal of the N > 1 path on a box with fewer GPUs than ranks: ranks share devices and
+        # the top-k all-gather goes through gloo on the host (the product path is RCCL: --backend nccl)
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from morna_amd import build as hip_build
     if rank == 0:
@@ -173,7 +183,7 @@ def main():
     index.timer_enable(False)
     timers = index.timers()
     if world > 1:
-        t = torch.tensor([elapsed, tb, tq], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, tb, tq], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, tb, tq = [float(x) for x in t.tolist()]
     st = index.forest_stats()

@@ -22,17 +22,19 @@ def merge_topk(ids, dists, k):
     flat_d = np.transpose(dists, (1, 0, 2)).reshape(nq, world * kk)
     flat_d = np.where(flat_ids < 0, np.inf, flat_d)
     key_ids = np.where(flat_ids < 0, np.iinfo(np.int64).max, flat_ids)
-    out_ids = np.full((nq, k), -1, np.int64)
-    out_d = np.full((nq, k), np.inf, flat_d.dtype)
-    counts = np.zeros(nq, np.int32)
-    for q in range(nq):
-        order = np.lexsort((key_ids[q], flat_d[q]))[:k]       # primary distance, then id: annoy's pair sort
-        valid = flat_ids[q][order] >= 0
-        m = int(valid.sum())
-        out_ids[q, :m] = flat_ids[q][order][:m]
-        out_d[q, :m] = flat_d[q][order][:m]
-        counts[q] = m
-    return out_ids, out_d, counts
+    if nq == 0:
+        return np.full((0, k), -1, np.int64), np.full((0, k), np.inf, flat_d.dtype), np.zeros(0, np.int32)
+    # primary distance, then id: annoy's pair sort; empty slots (inf, max id) sort last
+    order = np.lexsort((key_ids, flat_d), axis=1)[:, :k]
+    out_ids = np.take_along_axis(flat_ids, order, axis=1)
+    out_d = np.take_along_axis(flat_d, order, axis=1)
+    if out_ids.shape[1] < k:                                   # fewer slots than k in total
+        pad = k - out_ids.shape[1]
+        out_ids = np.concatenate([out_ids, np.full((nq, pad), -1, np.int64)], axis=1)
+        out_d = np.concatenate([out_d, np.full((nq, pad), np.inf, out_d.dtype)], axis=1)
+    counts = (out_ids >= 0).sum(axis=1).astype(np.int32)
+    out_d = np.where(out_ids >= 0, out_d, np.inf)
+    return out_ids.astype(np.int64), out_d, counts
 
 
 class ShardedSearch(object):
