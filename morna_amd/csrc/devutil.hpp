@@ -168,13 +168,27 @@ __device__ inline float wave_dot_finish(float a0, float a1, float a2, float a3)
     return wave_sum_lane0((a0 + a1) + (a2 + a3));
 }
 
-#define FMA4(acc, xv, yv)                         \
-    do {                                          \
-        acc##0 = __builtin_fmaf(xv.x, yv.x, acc##0); \
-        acc##1 = __builtin_fmaf(xv.y, yv.y, acc##1); \
-        acc##2 = __builtin_fmaf(xv.z, yv.z, acc##2); \
-        acc##3 = __builtin_fmaf(xv.w, yv.w, acc##3); \
-    } while (0)
+// The lane's four fmaf chains, held as two register PAIRS (chains 0,1 and 2,3) so that each
+// k-step is two v_pk_fma_f32 on the (x,y) and (z,w) halves of the float4 operands as they
+// sit in registers -- no operand shuffling.  Each component is an IEEE fmaf, exactly the
+// scalar chains of the contract.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct Acc4 {
+    f32x2 lo, hi;
+};
+__device__ inline Acc4 acc4_zero()
+{
+    Acc4 a;
+    a.lo = (f32x2){0.f, 0.f};
+    a.hi = (f32x2){0.f, 0.f};
+    return a;
+}
+__device__ inline void fma4(Acc4 &a, const float4 &x, const float4 &y)
+{
+    a.lo = __builtin_elementwise_fma((f32x2){x.x, x.y}, (f32x2){y.x, y.y}, a.lo);
+    a.hi = __builtin_elementwise_fma((f32x2){x.z, x.w}, (f32x2){y.z, y.w}, a.hi);
+}
+__device__ inline float acc4_finish(const Acc4 &a) { return wave_dot_finish(a.lo.x, a.lo.y, a.hi.x, a.hi.y); }
 
 // Canonical dot of two vectors of nvec float4 (both 16-byte aligned, zero padded
 // to a multiple of 4 floats).  All 64 lanes of the wave must call it; every lane
@@ -183,22 +197,22 @@ __device__ inline float wave_dot_finish(float a0, float a1, float a2, float a3)
 template <typename PA, typename PB>
 __device__ inline float wave_dot(PA a, PB b, int nvec, int lane)
 {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    Acc4 s = acc4_zero();
     int i = lane;
     // 4 independent 1-KiB loads in flight per operand before the first use
     for (; i + 3 * WAVE < nvec; i += 4 * WAVE) {
         float4 x0 = a[i], x1 = a[i + WAVE], x2 = a[i + 2 * WAVE], x3 = a[i + 3 * WAVE];
         float4 y0 = b[i], y1 = b[i + WAVE], y2 = b[i + 2 * WAVE], y3 = b[i + 3 * WAVE];
-        FMA4(s, x0, y0);
-        FMA4(s, x1, y1);
-        FMA4(s, x2, y2);
-        FMA4(s, x3, y3);
+        fma4(s, x0, y0);
+        fma4(s, x1, y1);
+        fma4(s, x2, y2);
+        fma4(s, x3, y3);
     }
     for (; i < nvec; i += WAVE) {
         float4 x = a[i], y = b[i];
-        FMA4(s, x, y);
+        fma4(s, x, y);
     }
-    return wave_dot_finish(s0, s1, s2, s3);
+    return acc4_finish(s);
 }
 
 // 64-bit butterfly helpers for (key) reductions

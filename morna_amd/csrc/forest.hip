@@ -192,10 +192,10 @@ __global__ __launch_bounds__(TM_THREADS) void two_means_kernel(const float *__re
 template <int NV>
 __device__ inline float reg_dot(const float4 (&a)[NV], const float4 (&b)[NV])
 {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    Acc4 s = acc4_zero();
 #pragma unroll
-    for (int k = 0; k < NV; k++) FMA4(s, a[k], b[k]);   // pad elements are 0 in both: fmaf(0, 0, s) == s
-    return wave_dot_finish(s0, s1, s2, s3);
+    for (int k = 0; k < NV; k++) fma4(s, a[k], b[k]);   // pad elements are 0 in both: fmaf(0, 0, s) == s
+    return acc4_finish(s);
 }
 
 // rows are padded to NV * 256 floats exactly (dpad is a multiple of 256): no lane is ever idle
@@ -491,13 +491,13 @@ __global__ __launch_bounds__(RW_THREADS) void split_rw_kernel(
                 const int p = __builtin_amdgcn_readlane(mp, gi);
                 const int s = a - a0;
                 const float4 *hv = hs + s * nvec;
-                float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+                Acc4 c = acc4_zero();
                 float4 h4[NV];
 #pragma unroll
                 for (int k = 0; k < NV; k++) h4[k] = hv[lane + k * WAVE];
 #pragma unroll
-                for (int k = 0; k < NV; k++) FMA4(c, xr[k], h4[k]);
-                const float d = wave_dot_finish(c0, c1, c2, c3);
+                for (int k = 0; k < NV; k++) fma4(c, xr[k], h4[k]);
+                const float d = acc4_finish(c);
                 const int sd = d != 0.f ? (d > 0.f) : pos_flip(s_seed[s], (uint32_t)p);
                 if (lane == 0) {
                     side[(int64_t)(t0 + gi) * n_items + s_start[s] + p] = (uint8_t)sd;
