@@ -416,7 +416,7 @@ __global__ __launch_bounds__(SP_THREADS) void split_kernel(const float *__restri
 
 #define RW_THREADS 512    // 1024 caps the kernel at 128 VGPRs and spills the two row buffers
 #define RW_WAVES (RW_THREADS / WAVE)
-#define RW_ROWS 64
+#define RW_ROWS 256   // rows per window: the hyperplane staging is paid once per 16 rows of every wave
 #define RW_SLOTS 8
 
 // inverse of the permutation restricted to the tasks: row -> (task index, position in segment)
@@ -436,7 +436,7 @@ __global__ void invert_kernel(const SplitTask *__restrict__ tasks, const int2 *_
     }
 }
 
-template <int NV>   // float4 per lane that hold one row: ceil(dpad / 256)
+template <int NV, int GT>   // NV float4 per lane hold one row (dpad / 256); GT trees per group
 __global__ __launch_bounds__(RW_THREADS) void split_rw_kernel(
     const float *__restrict__ X, int64_t n_items, int32_t dpad, const SplitTask *__restrict__ tasks,
     const int32_t *__restrict__ tree_first /* [n_trees + 1] */, int32_t n_trees, int32_t G,
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(RW_THREADS) void split_rw_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *hs = (float4 *)smem;   // [RW_SLOTS][nvec]
-    __shared__ int s_ones[RW_SLOTS], s_start[RW_SLOTS];
+    __shared__ int s_ones[RW_SLOTS], s_start[RW_SLOTS], s_hp[RW_SLOTS];
     __shared__ uint32_t s_seed[RW_SLOTS];
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
@@ -457,15 +457,19 @@ __global__ __launch_bounds__(RW_THREADS) void split_rw_kernel(
     if (win >= n_windows) return;
     const int t0 = g * G, t1 = (t0 + G) < n_trees ? (t0 + G) : n_trees;
     const int a0 = tree_first[t0], nslots = tree_first[t1] - a0;   // <= RW_SLOTS by construction
-    for (int s = 0; s < nslots; s++) {
-        const float4 *src = (const float4 *)(hp + (int64_t)tasks[a0 + s].slot * dpad);
-        for (int v = tid; v < nvec; v += RW_THREADS) hs[s * nvec + v] = src[v];
-    }
     if (tid < nslots) {
         const SplitTask t = tasks[a0 + tid];
         s_ones[tid] = 0;
         s_start[tid] = t.start;
+        s_hp[tid] = t.slot;
         s_seed[tid] = node_seed(seed, (uint32_t)t.tree, (uint32_t)t.level, (uint32_t)t.start, (uint32_t)t.attempt);
+    }
+    __syncthreads();
+    // stage the group's hyperplanes as ONE flat copy: only one workgroup fits a CU, nothing else
+    // would hide a slot-by-slot chain of dependent loads
+    for (int idx = tid; idx < nslots * nvec; idx += RW_THREADS) {
+        const int s = idx / nvec, v = idx - s * nvec;
+        hs[idx] = ((const float4 *)(hp + (int64_t)s_hp[s] * dpad))[v];
     }
     __syncthreads();
     if (nslots > 0) {
@@ -484,43 +488,62 @@ __global__ __launch_bounds__(RW_THREADS) void split_rw_kernel(
                 mp = row_pos[(int64_t)(t0 + lane) * n_items + row];
             }
         };
+        // the row against its node's hyperplane in every tree of the group, branch-free and with k
+        // outermost: GT independent FMA chains and reductions are in flight, a tree that does not
+        // own the row reads slot 0 and its result is dropped
         auto process = [&](const float4(&xr)[NV], int ma, int mp) {
-            for (int gi = 0; gi < ng; gi++) {
-                const int a = __builtin_amdgcn_readlane(ma, gi);   // v_readlane: gi is wave-uniform
-                if (a < 0) continue;
-                const int p = __builtin_amdgcn_readlane(mp, gi);
-                const int s = a - a0;
-                const float4 *hv = hs + s * nvec;
-                Acc4 c = acc4_zero();
-                float4 h4[NV];
+            int a[GT], p[GT];
+            const float4 *hv[GT];
+            Acc4 c[GT];
 #pragma unroll
-                for (int k = 0; k < NV; k++) h4[k] = hv[lane + k * WAVE];
+            for (int gi = 0; gi < GT; gi++) {
+                a[gi] = __builtin_amdgcn_readlane(ma, gi);   // v_readlane: lanes >= ng hold -1
+                p[gi] = __builtin_amdgcn_readlane(mp, gi);
+                hv[gi] = hs + (a[gi] < 0 ? 0 : a[gi] - a0) * nvec + lane;
+                c[gi] = acc4_zero();
+            }
 #pragma unroll
-                for (int k = 0; k < NV; k++) fma4(c, xr[k], h4[k]);
-                const float d = acc4_finish(c);
-                const int sd = d != 0.f ? (d > 0.f) : pos_flip(s_seed[s], (uint32_t)p);
+            for (int k = 0; k < NV; k++) {
+#pragma unroll
+                for (int gi = 0; gi < GT; gi++) fma4(c[gi], xr[k], hv[gi][k * WAVE]);
+            }
+            float d[GT];
+#pragma unroll
+            for (int gi = 0; gi < GT; gi++) d[gi] = acc4_finish(c[gi]);
+#pragma unroll
+            for (int gi = 0; gi < GT; gi++) {
+                if (a[gi] < 0) continue;
+                const int s = a[gi] - a0;
+                const int sd = d[gi] != 0.f ? (d[gi] > 0.f) : pos_flip(s_seed[s], (uint32_t)p[gi]);
                 if (lane == 0) {
-                    side[(int64_t)(t0 + gi) * n_items + s_start[s] + p] = (uint8_t)sd;
+                    side[(int64_t)(t0 + gi) * n_items + s_start[s] + p[gi]] = (uint8_t)sd;
                     if (sd) atomicAdd(&s_ones[s], 1);
                 }
             }
         };
         auto valid = [&](int rr) { return rr < RW_ROWS && row_base + rr < n_items; };
-        float4 xa[NV], xb[NV];
-        int ma_a = -1, mp_a = 0, ma_b = -1, mp_b = 0;
+        // three row buffers in rotation: a row is requested two rows before it is used
+        float4 xa[NV], xb[NV], xc[NV];
+        int ma_a = -1, mp_a = 0, ma_b = -1, mp_b = 0, ma_c = -1, mp_c = 0;
         int rr = w;
         if (valid(rr)) {
             load_row(rr, xa, ma_a, mp_a);
+            bool vb = valid(rr + RW_WAVES);
+            if (vb) load_row(rr + RW_WAVES, xb, ma_b, mp_b);
             for (;;) {
-                const bool vb = valid(rr + RW_WAVES);
-                if (vb) load_row(rr + RW_WAVES, xb, ma_b, mp_b);
+                const bool vc = vb && valid(rr + 2 * RW_WAVES);
+                if (vc) load_row(rr + 2 * RW_WAVES, xc, ma_c, mp_c);
                 process(xa, ma_a, mp_a);
                 if (!vb) break;
-                const bool va = valid(rr + 2 * RW_WAVES);
-                if (va) load_row(rr + 2 * RW_WAVES, xa, ma_a, mp_a);
+                const bool va = vc && valid(rr + 3 * RW_WAVES);
+                if (va) load_row(rr + 3 * RW_WAVES, xa, ma_a, mp_a);
                 process(xb, ma_b, mp_b);
+                if (!vc) break;
+                vb = va && valid(rr + 4 * RW_WAVES);
+                if (vb) load_row(rr + 4 * RW_WAVES, xb, ma_b, mp_b);
+                process(xc, ma_c, mp_c);
                 if (!va) break;
-                rr += 2 * RW_WAVES;
+                rr += 3 * RW_WAVES;
             }
         }
     }
@@ -783,10 +806,10 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             for (int t = 0; t < n_trees; t++)
                 max_per_tree = std::max(max_per_tree, tree_first[(size_t)t + 1] - tree_first[(size_t)t]);
             const int nv = (dpad / 4 + WAVE - 1) / WAVE;
-            // measured on MI355X (C3, 1e7 rows per level): 3.4 / 4.3 / 5.9 ms with 1 / 2 / 4 nodes per tree
-            // against 4.6 ms for the chunk form, so it is used while a tree has at most 2 split nodes
-            // (MORNA_SPLIT_RW=0 turns it off, =4 extends it to 4 nodes per tree)
-            static const int rw_max = getenv("MORNA_SPLIT_RW") ? atoi(getenv("MORNA_SPLIT_RW")) : 2;
+            // measured on MI355X (C3, 1e7 rows per level): 2.4 / 2.8 / 3.8 ms with 1 / 2 / 4 nodes per tree
+            // against 4.7 ms for the chunk form, so it is used while a tree has at most 4 split nodes
+            // (MORNA_SPLIT_RW=0 turns it off, =2 restricts it to 2 nodes per tree)
+            static const int rw_max = getenv("MORNA_SPLIT_RW") ? atoi(getenv("MORNA_SPLIT_RW")) : 4;
             const bool nv_ok = nv == 1 || nv == 2 || nv == 3 || nv == 4 || nv == 6 || nv == 8 || nv == 12;
             const bool use_rw = attempt == 0 && max_per_tree >= 1 && max_per_tree <= std::min(rw_max, RW_SLOTS / 2) &&
                                 nv_ok && rows * 2 >= (int64_t)n_trees * N;
@@ -802,12 +825,19 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 ScopedTimer tm(h, MORNA_T_SPLIT, 4 * (int64_t)D * (rows + A));
                 const unsigned grid = 8u * (unsigned)((n_windows + 7) / 8) * (unsigned)n_groups;
                 const size_t lds = (size_t)RW_SLOTS * dpad * 4;
-#define RW_LAUNCH(NVV)                                                                                                   \
+#define RW_LAUNCH_G(NVV, GTT)                                                                                            \
     do {                                                                                                                 \
-        F_TRY(hipFuncSetAttribute((const void *)split_rw_kernel<NVV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(split_rw_kernel<NVV>, dim3(grid), dim3(RW_THREADS), lds, h->stream, h->X.p, N, dpad, d_tasks.p,  \
-                           d_tree_first.p, n_trees, G, row_task.p, row_pos.p, seed, hp_level, side.p, d_ones.p, n_windows, \
-                           n_groups);                                                                                    \
+        F_TRY(hipFuncSetAttribute((const void *)split_rw_kernel<NVV, GTT>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                  (int)lds));                                                                            \
+        hipLaunchKernelGGL((split_rw_kernel<NVV, GTT>), dim3(grid), dim3(RW_THREADS), lds, h->stream, h->X.p, N, dpad,     \
+                           d_tasks.p, d_tree_first.p, n_trees, G, row_task.p, row_pos.p, seed, hp_level, side.p, d_ones.p, \
+                           n_windows, n_groups);                                                                         \
+    } while (0)
+#define RW_LAUNCH(NVV)                          \
+    do {                                        \
+        if (G == 8) RW_LAUNCH_G(NVV, 8);        \
+        else if (G == 4) RW_LAUNCH_G(NVV, 4);   \
+        else RW_LAUNCH_G(NVV, 2);               \
     } while (0)
                 if (nv == 1) RW_LAUNCH(1);
                 else if (nv == 2) RW_LAUNCH(2);
@@ -817,6 +847,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 else if (nv == 8) RW_LAUNCH(8);
                 else RW_LAUNCH(12);
 #undef RW_LAUNCH
+#undef RW_LAUNCH_G
             } else {
                 // algorithmic bytes: 4*D*sum|node| + 4*D*#split nodes
                 ScopedTimer tm(h, MORNA_T_SPLIT, 4 * (int64_t)D * (rows + A));
