@@ -47,8 +47,8 @@ def parse():
     ap.add_argument("--junctions", type=int, default=70_000,
                     help="junction lines; 70k gives nnz ~ 2000 per sample (SURVEY.md 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-trees", type=int, default=2)
-    ap.add_argument("--cpu-queries", type=int, default=50)
+    ap.add_argument("--cpu-trees", type=int, default=24)
+    ap.add_argument("--cpu-queries", type=int, default=200)
     ap.add_argument("--verify", action="store_true", help="check results against the exact search")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend; nccl (= RCCL) is the product path, gloo only rehearses "
@@ -62,7 +62,7 @@ def cpu_baseline(args, data, prep, items):
     N, D = prep["n_items"], args.features
     # (1) feature accumulation on a prefix of the junction lines (~1/8 of nnz)
     J = len(data["keys"])
-    Js = max(1, J // 8)
+    Js = max(1, J // 2)
     nnz_s = int(data["row_ptr"][Js])
     buf, off = capi.pack_keys(data["keys"][:Js])
     t0 = time.perf_counter()
@@ -224,7 +224,7 @@ def main():
             "forest": {"n_nodes": st["n_nodes"], "n_split": st["n_split"], "max_depth": st["max_depth"],
                        "split_rows": st["split_rows"], "split_attempts": st["split_attempts"],
                        "fallback_nodes": st["fallback_nodes"]},
-            "roofline": {"kernel": "split_kernel (+ split_rw_kernel, its row-window form at the two shallowest levels)",
+            "roofline": {"kernel": "split_kernel (+ split_rw_kernel, its row-window form at the three shallowest levels)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "launches": sp["launches"] // max(args.steps, 1),
