@@ -119,7 +119,10 @@ def main():
         # the top-k all-gather goes through gloo on the host (the product path is RCCL: --backend nccl)
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # MORNA_BENCH_FORCE_SHARDED=1 (under torchrun, one rank): run the sharded query path on a 1-rank
+    # group, to price its collectives and hand-overs on a single-GPU box
+    force_sharded = bool(os.environ.get("MORNA_BENCH_FORCE_SHARDED")) and "RANK" in os.environ
+    if world > 1 or force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -143,7 +146,7 @@ def main():
     index = AnnoyIndex(D, device=local_rank)
     index.stage_junctions(prep["key_bytes"], prep["key_off"], prep["row_ptr"], prep["ids"], prep["cov"], prep["idf"])
     items = query_items(n_items, Q)              # the queries this rank owns (all of them when world == 1)
-    sharded = ShardedSearch(index, rank, world, n_items) if world > 1 else None
+    sharded = ShardedSearch(index, rank, world, n_items) if (world > 1 or force_sharded) else None
     if sharded is not None:
         items = items[rank::world]
 
@@ -246,7 +249,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

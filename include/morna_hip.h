@@ -98,7 +98,7 @@ int morna_lines_free(morna_lines *L);
 int64_t morna_get_n_items(const morna_index *h);
 /* AnnoyIndex.get_item_vector(i)                                morna.py:702 */
 int morna_get_item_vector(morna_index *h, int32_t id, float *out);
-/* rows of several items at once: out[n][dim] (query vectors of a row-sharded search) */
+/* rows of several items at once: out[n][dim], host or device memory (query vectors of a row-sharded search) */
 int morna_get_item_vectors(morna_index *h, const int32_t *ids, int64_t n, float *out);
 /* whole matrix / squared norms, for tests */
 int morna_get_items(morna_index *h, float *rows_out /* [n][dim] */);
@@ -132,6 +132,8 @@ int morna_get_forest(morna_index *h, int32_t *node_rec, int32_t *perm, float *hy
  * AnnoyIndex.get_nns_by_vector(v, n, search_k, include_distances)  morna.py:651, 659
  * batched over nq queries; q[nq][dim] fp32.  search_k = -1 -> k * n_trees.
  * ids_out[nq][k] (-1 padded), dist_out[nq][k] (may be NULL), count_out[nq] (may be NULL).
+ * q may also point to memory of the handle's device (the row-sharded search hands over the
+ * all-gathered query rows without a trip through the host); the outputs are host memory.
  */
 int morna_get_nns_by_vector(morna_index *h, const float *q, int64_t nq, int32_t k, int32_t search_k,
                             int32_t *ids_out, float *dist_out, int32_t *count_out);

@@ -64,6 +64,20 @@ class AnnoyIndex(object):
         check(lib().morna_get_item_vectors(self._h, ptr(ids), len(ids), ptr(out)))
         return out
 
+    def get_item_vectors_into(self, ids, out_ptr):
+        """Rows of `ids` written to out_ptr: [len(ids), f] fp32 in HOST or this DEVICE's memory."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        check(lib().morna_get_item_vectors(self._h, ptr(ids), len(ids), C.c_void_p(int(out_ptr))))
+
+    def get_nns_by_vector_ptr(self, q_ptr, nq, n, search_k=-1):
+        """get_nns_by_vector_batch for nq contiguous fp32 rows at a raw (host or device) address."""
+        ids = np.empty((nq, n), np.int32)
+        d = np.empty((nq, n), np.float32)
+        cnt = np.empty(nq, np.int32)
+        check(lib().morna_get_nns_by_vector(self._h, C.c_void_p(int(q_ptr)), int(nq), int(n), int(search_k),
+                                            ptr(ids), ptr(d), ptr(cnt)))
+        return ids, d, cnt
+
     def get_items(self):
         out = np.empty((self.get_n_items(), self.f), dtype=np.float32)
         check(lib().morna_get_items(self._h, ptr(out)))

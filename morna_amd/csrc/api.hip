@@ -62,7 +62,16 @@ void resolve_timers(morna_index *h)
 
 using namespace morna;
 
-#define CHECK_H(h)                              \
+// rows ids[b] of the padded matrix -> packed [n][dim]
+__global__ void gather_rows_kernel(const float *__restrict__ X, const int32_t *__restrict__ ids, int32_t dim,
+                                   int32_t dpad, float *__restrict__ out)
+{
+    const float *src = X + (int64_t)ids[blockIdx.x] * dpad;
+    float *dst = out + (int64_t)blockIdx.x * dim;
+    for (int z = threadIdx.x; z < dim; z += blockDim.x) dst[z] = src[z];
+}
+
+#define CHECK_H(h)                            \
     if (!(h)) {                                 \
         set_error("null index handle");         \
         return MORNA_E_INVALID;                 \
@@ -285,9 +294,17 @@ int morna_get_item_vectors(morna_index *h, const int32_t *ids, int64_t n, float 
             set_error("Item index %d out of range [0, %lld)", ids[i], (long long)h->n_items);
             return MORNA_E_RANGE;
         }
-    for (int64_t i = 0; i < n; i++)
-        HIP_TRY(hipMemcpyAsync(out + i * h->dim, h->X.p + (size_t)ids[i] * h->dpad, (size_t)h->dim * 4,
-                               hipMemcpyDeviceToHost, h->stream));
+    if (n <= 0) return MORNA_OK;
+    // one gather launch into a packed [n][dim] staging image, then ONE copy to `out`
+    // (host or device memory): a memcpy per row costs microseconds of launch each
+    const size_t idb = ((size_t)n * 4 + 255) / 256 * 256;
+    MORNA_TRY(h->ws.alloc(idb + (size_t)n * h->dim * 4));
+    int32_t *d_ids = (int32_t *)h->ws.p;
+    float *d_rows = (float *)(h->ws.p + idb);
+    HIP_TRY(hipMemcpyAsync(d_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n), dim3(256), 0, h->stream, h->X.p, d_ids, h->dim, h->dpad, d_rows);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d_rows, (size_t)n * h->dim * 4, hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return MORNA_OK;
 }
@@ -377,7 +394,7 @@ int morna_get_nns_by_vector(morna_index *h, const float *q, int64_t nq, int32_t 
         return MORNA_E_INVALID;
     }
     HIP_TRY(hipSetDevice(h->device));
-    return query_batch(h, q, nullptr, nq, k, search_k, ids_out, dist_out, count_out);
+    return query_batch(h, q, 0, nullptr, nq, k, search_k, ids_out, dist_out, count_out);
 }
 
 int morna_get_nns_by_item(morna_index *h, const int32_t *items, int64_t nq, int32_t k, int32_t search_k,
@@ -389,7 +406,7 @@ int morna_get_nns_by_item(morna_index *h, const int32_t *items, int64_t nq, int3
         return MORNA_E_INVALID;
     }
     HIP_TRY(hipSetDevice(h->device));
-    return query_batch(h, nullptr, items, nq, k, search_k, ids_out, dist_out, count_out);
+    return query_batch(h, nullptr, 0, items, nq, k, search_k, ids_out, dist_out, count_out);
 }
 
 int morna_exact_search(morna_index *h, const double *q, int64_t nq, int32_t k, int32_t *ids_out, double *dist_out,

@@ -182,7 +182,7 @@ int build_features(morna_index *h, int64_t n_items);
 int hash_keys_device(morna_index *h, const uint8_t *key_bytes, const int64_t *key_off, int64_t J,
                      int32_t *hash_out, int32_t *col_out, int32_t *sign_out);
 int build_forest(morna_index *h, int32_t n_trees, uint32_t seed);
-int query_batch(morna_index *h, const float *q_host, const int32_t *items_host, int64_t nq, int32_t k,
+int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int32_t *items_host, int64_t nq, int32_t k,
                 int32_t search_k, int32_t *ids_out, float *dist_out, int32_t *count_out);
 int exact_search(morna_index *h, const double *q, int64_t nq, int32_t k, int32_t *ids_out,
                  double *dist_out, int32_t *count_out);

@@ -6,14 +6,18 @@
 //
 // All n_trees trees advance one level per round.  A tree is a permutation of the
 // item ids (perm[tree][N]); a node is a contiguous segment of it.  Per level:
-//   two_means_kernel  one workgroup per split node: 200 sequential centroid
-//                     updates on LDS-resident centroids, rows prefetched one
-//                     iteration ahead (the Kiss32 stream does not depend on data)
-//   split_kernel      THE bandwidth kernel: every row of every split node is
-//                     streamed once from HBM and dotted (wavefront dot product,
-//                     hyperplane resident in LDS) against its node's hyperplane;
-//                     lane 0 records the side, one integer atomic per workgroup
-//                     counts the right-hand rows
+//   two_means_wave_kernel  one WAVE per split node, centroids / current row / next
+//                     row in registers: 200 sequential centroid updates, the row of
+//                     step l+1 in flight during step l (the Kiss32 stream does not
+//                     depend on data).  two_means_kernel is its LDS form (one
+//                     workgroup per node) for rows too long for the register file.
+//   split_kernel      every row of every split node is dotted (wavefront dot product,
+//                     hyperplane resident in LDS) against its node's hyperplane, one
+//                     workgroup per 64 positions of a node; launch order sorted by row
+//                     id, one run per XCD, so the trees' re-reads hit L2.
+//   split_rw_kernel   the same work at shallow levels (<= 4 split nodes per tree) as
+//                     row windows x tree groups: a row is loaded once into registers
+//                     and used for every tree of the group.
 //   (host)            annoy's 3-attempt / 0.95 imbalance rule on the counts
 //   fallback_kernel   random sides for nodes still above 0.99
 //   partition_kernel  stable partition of each segment by side
@@ -408,16 +412,16 @@ __global__ __launch_bounds__(SP_THREADS) void split_kernel(const float *__restri
 }
 
 // ---- shallow levels: row-window form of the split kernel ---------------------------
-// While a tree has at most RW_SLOTS / G split nodes, a workgroup takes a WINDOW of 64
+// While a tree has at most RW_SLOTS / G split nodes, a workgroup takes a WINDOW of RW_ROWS
 // consecutive row ids and a GROUP of G trees: the <= RW_SLOTS hyperplanes those trees
 // can need sit in LDS, each wave loads a row ONCE into registers and dots it against
 // the hyperplane of its node in every tree of the group.  L2 -> CU traffic per
 // (row, tree) drops from one row to 1/G row; same wave_dot order, same results.
 
-#define RW_THREADS 512    // 1024 caps the kernel at 128 VGPRs and spills the two row buffers
+#define RW_THREADS 512    // 1024 caps the kernel at 128 VGPRs and spills the row buffers
 #define RW_WAVES (RW_THREADS / WAVE)
-#define RW_ROWS 256   // rows per window: the hyperplane staging is paid once per 16 rows of every wave
-#define RW_SLOTS 8
+#define RW_ROWS 256       // rows per window: the hyperplane staging is paid once per 32 rows of every wave
+#define RW_SLOTS 8        // hyperplanes resident in LDS (96 KB at D = 3000): one workgroup per CU
 
 // inverse of the permutation restricted to the tasks: row -> (task index, position in segment)
 __global__ void invert_kernel(const SplitTask *__restrict__ tasks, const int2 *__restrict__ info /* task per chunk */,
@@ -704,7 +708,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
     // (and is kept across rebuilds); slot = n_split_total + index within the level
     int64_t n_split_total = 0;
     int rc = MORNA_OK;
-    std::vector<SplitTask> tasks, pend;
+    std::vector<SplitTask> tasks;
     std::vector<int32_t> h_ones;
     int32_t level = 0;
 

@@ -201,9 +201,11 @@ __global__ __launch_bounds__(Q_THREADS) void query_kernel(QueryParams P)
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-int query_batch(morna_index *h, const float *q_host, const int32_t *items_host, int64_t nq, int32_t k,
+// q_host: query vectors in host OR device memory (unified addressing), q_stride floats apart (0 = dim)
+int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int32_t *items_host, int64_t nq, int32_t k,
                 int32_t search_k, int32_t *ids_out, float *dist_out, int32_t *count_out)
 {
+    if (q_stride <= 0) q_stride = h->dim;
     if (!h->built) {
         set_error("index has not been built: call build() before searching");
         return MORNA_E_STATE;
@@ -261,8 +263,8 @@ int query_batch(morna_index *h, const float *q_host, const int32_t *items_host, 
         P.Q = nullptr; P.items = nullptr;
         if (q_host) {
             HIP_TRY(hipMemsetAsync(Qd, 0, (size_t)nb * h->dpad * 4, h->stream));
-            HIP_TRY(hipMemcpy2DAsync(Qd, (size_t)h->dpad * 4, q_host + q0 * h->dim, (size_t)h->dim * 4,
-                                     (size_t)h->dim * 4, (size_t)nb, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpy2DAsync(Qd, (size_t)h->dpad * 4, q_host + q0 * q_stride, (size_t)q_stride * 4,
+                                     (size_t)h->dim * 4, (size_t)nb, hipMemcpyDefault, h->stream));
             P.Q = Qd;
         } else {
             HIP_TRY(hipMemcpyAsync(d_items.p, items_host + q0, (size_t)nb * 4, hipMemcpyHostToDevice, h->stream));

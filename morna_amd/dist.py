@@ -57,14 +57,25 @@ class ShardedSearch(object):
         dist.all_gather(outs, t, group=self.group)
         return np.stack([o.cpu().numpy() for o in outs])
 
+    def _gather_merge(self, ids, d, k):
+        """All-gather of the per-shard top-k -- the one collective on the data path -- as a single
+        [nq, 2k] int32 message per rank (global ids, then the fp32 distance bits), then the merge."""
+        gids = np.where(ids >= 0, ids.astype(np.int64) + self.offsets[self.rank], -1)
+        if self.n_total < 2 ** 31:
+            packed = np.concatenate([gids.astype(np.int32), np.ascontiguousarray(d, np.float32).view(np.int32)], axis=1)
+            allp = self._all_gather_np(packed)
+            all_ids = allp[:, :, :ids.shape[1]].astype(np.int64)
+            all_d = np.ascontiguousarray(allp[:, :, ids.shape[1]:]).view(np.float32)
+        else:
+            all_ids = self._all_gather_np(gids)
+            all_d = self._all_gather_np(np.ascontiguousarray(d, np.float32))
+        return merge_topk(all_ids, all_d, k)
+
     def get_nns_by_vector(self, Q, k, search_k=-1):
         """Q: [nq, f] fp32, identical on every rank.  Returns merged global ids,
         distances and counts on every rank."""
         ids, d, cnt = self.index.get_nns_by_vector_batch(Q, k, search_k)
-        gids = np.where(ids >= 0, ids.astype(np.int64) + self.offsets[self.rank], -1)
-        all_ids = self._all_gather_np(gids)            # the one collective on the data path
-        all_d = self._all_gather_np(d.astype(np.float32))
-        return merge_topk(all_ids, all_d, k)
+        return self._gather_merge(ids, d, k)
 
     def get_nns_by_local_items(self, items, k, search_k=-1):
         """Each rank contributes the rows of some of its own items as queries
@@ -74,7 +85,19 @@ class ShardedSearch(object):
         dist.all_gather(n_each, torch.tensor([len(items)], dtype=torch.int64, device=self.device), group=self.group)
         n_each = [int(x.item()) for x in n_each]
         n_max = max(n_each)
-        mine = np.zeros((n_max, self.index.f), np.float32)
+        f = self.index.f
+        if self.device.type == "cuda" and hasattr(self.index, "get_nns_by_vector_ptr"):
+            # RCCL path: the query rows go HBM -> xGMI -> HBM, never through the host
+            mine = torch.zeros((n_max, f), dtype=torch.float32, device=self.device)
+            if len(items):
+                self.index.get_item_vectors_into(items, mine.data_ptr())       # synchronises the library's stream
+            outs = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(outs, mine, group=self.group)                       # query vectors: nq * D * 4 bytes, once
+            Q = torch.cat([outs[g][:n_each[g]] for g in range(self.world)], dim=0).contiguous()
+            torch.cuda.current_stream().synchronize()                          # the library reads Q on its own stream
+            ids, d, cnt = self.index.get_nns_by_vector_ptr(Q.data_ptr(), Q.shape[0], k, search_k)
+            return self._gather_merge(ids, d, k)
+        mine = np.zeros((n_max, f), np.float32)
         if len(items):
             mine[:len(items)] = self.index.get_item_vectors(items)
         allq = self._all_gather_np(mine)               # query vectors: nq * D * 4 bytes, once

@@ -321,6 +321,40 @@ def test_recall_matches_faithful_annoy_restatement(capi):
     assert hit_g / (k * len(items)) >= hit_o / (k * len(items)) - 0.05
 
 
+def test_sharded_search_device_path_one_rank_rccl():
+    """The RCCL path of morna_amd/dist.py on a 1-rank group: query rows stay in HBM
+    (device-pointer hand-over), top-k all-gather, merge -- must equal the plain by-item search."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from morna_amd.annoy import AnnoyIndex
+    from morna_amd.dist import ShardedSearch
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.default_rng(12)
+        X = _clustered(rng, 3000, 40)
+        a = AnnoyIndex(40)
+        a.add_items(X)
+        a.build(6)
+        ss = ShardedSearch(a, 0, 1, 3000)
+        items = rng.choice(3000, 77, replace=False).astype(np.int32)
+        ids, d, cnt = ss.get_nns_by_local_items(items, 10, -1)
+        want = a.get_nns_by_item_batch(items, 10, -1)
+        assert ids.tolist() == want[0].astype(np.int64).tolist()
+        assert d.astype(np.float32).tobytes() == want[1].tobytes() and cnt.tolist() == want[2].tolist()
+        ids2, _, _ = ss.get_nns_by_vector(X[items], 10, -1)
+        assert ids2.tolist() == ids.tolist()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_save_load_roundtrip(tmp_path):
     from morna_amd.annoy import AnnoyIndex
     rng = np.random.default_rng(4)
