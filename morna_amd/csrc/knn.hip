@@ -274,10 +274,14 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
             // algorithmic bytes = 4*D*(hyperplane dots + unique candidates + 1) per
             // query; the kernel counts them into d_stat[0], resolve_timers() prices them
             ScopedTimer tm(h, MORNA_T_QUERY, 0);
-            if (bm_lds)
+            if (bm_lds) {
+                if (lds > 48 * 1024)   // query image + sample bitmap can pass the default dynamic-LDS limit
+                    HIP_TRY(hipFuncSetAttribute((const void *)query_kernel<true>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(query_kernel<true>, dim3((unsigned)nb), dim3(Q_THREADS), lds, h->stream, P);
-            else
+            } else {
                 hipLaunchKernelGGL(query_kernel<false>, dim3((unsigned)nb), dim3(Q_THREADS), lds, h->stream, P);
+            }
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(ids_out + q0 * k, P.ids_out, (size_t)nb * k * 4, hipMemcpyDeviceToHost, h->stream));

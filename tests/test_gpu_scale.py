@@ -87,6 +87,34 @@ def test_full_size_forest_and_search_properties(N, D, T):
         assert np.allclose(ed[qi] ** 2, _true_ang(X, X[items[qi]], eids[qi]) ** 2, atol=1e-12)
 
 
+def test_many_items_tiny_rows_deep_trees():
+    """530k items x 4 features: K = 6, so trees are ~17 levels deep with ~10^5 nodes each, and the
+    sample bitmap of the query kernel no longer fits LDS (global-memory bitmap path).  Checked
+    against the oracle's wave-order restatement on a handful of queries, plus the invariants."""
+    from morna_amd.annoy import AnnoyIndex
+    from oracle import capi
+    rng = np.random.default_rng(7)
+    N, D, T = 530_000, 4, 2
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    a = AnnoyIndex(D)
+    a.add_items(X)
+    a.build(T)
+    st = _check_forest(a, N, T, D + 2)
+    assert st["max_depth"] >= 15
+    o = capi.AnnoyOracle(D, mode=1)
+    o.set_items(X)
+    o.build(T)
+    assert st["split_rows"] == o.split_rows() and st["split_attempts"] == o.split_nodes()
+    assert st["n_nodes"] == o.n_nodes()
+    items = rng.choice(N, 24, replace=False).astype(np.int32)
+    for n, sk in ((10, -1), (10, 5000), (100, 20000)):
+        ids, d, cnt = a.get_nns_by_item_batch(items, n, sk)
+        for qi, it in enumerate(items):
+            rid, rd = o.get_nns_by_item(int(it), n, sk, include_distances=True)
+            assert ids[qi, :int(cnt[qi])].tolist() == rid
+            assert d[qi, :int(cnt[qi])].tobytes() == np.array(rd, np.float32).tobytes()
+
+
 def test_feature_build_linearity_and_order_invariance():
     """50k-sample synthetic intropolis slice at D = 3000."""
     from morna_amd.annoy import AnnoyIndex
