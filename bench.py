@@ -144,7 +144,9 @@ def main():
     prep = prepare_csr(data["keys"], data["row_ptr"], data["samples"], data["cov"], data["sample_count"], 100)
     n_items = prep["n_items"]
     index = AnnoyIndex(D, device=local_rank)
+    t_stage = time.perf_counter()   # host -> HBM copy of the junction lines: NOT part of the timed region
     index.stage_junctions(prep["key_bytes"], prep["key_off"], prep["row_ptr"], prep["ids"], prep["cov"], prep["idf"])
+    t_stage = time.perf_counter() - t_stage
     items = query_items(n_items, Q)              # the queries this rank owns (all of them when world == 1)
     sharded = ShardedSearch(index, rank, world, n_items) if (world > 1 or force_sharded) else None
     if sharded is not None:
@@ -222,6 +224,9 @@ def main():
                        "parallelism": "rows sharded over %d GPU(s), RCCL all-gather of per-shard top-k" % world},
             "index_samples_per_sec": n_items * world * args.steps / tb,
             "queries_per_sec": Q * args.steps / tq,
+            # if the junction lines had to cross PCIe on every step (pageable host buffers, measured once)
+            "stage_ms": 1e3 * t_stage,
+            "samples_per_sec_pcie_inclusive": n_items * world / (elapsed / args.steps + t_stage),
             "build_ms_per_step": 1e3 * tb / args.steps, "query_ms_per_step": 1e3 * tq / args.steps,
             "kernel_ms_per_step": {n: round(v["ms"] / args.steps, 3) for n, v in timers.items()},
             "forest": {"n_nodes": st["n_nodes"], "n_split": st["n_split"], "max_depth": st["max_depth"],

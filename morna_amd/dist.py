@@ -37,6 +37,27 @@ def merge_topk(ids, dists, k):
     return out_ids.astype(np.int64), out_d, counts
 
 
+def merge_topk_exact(ids, dists, k):
+    """Merge of per-shard exact_search_nn results ([world, nq, k], fp64 distances): what the
+    reference's bisect_left scan over ALL rows would keep -- ascending distance, and among equal
+    distances the HIGHER global id first (morna.py:705-712).  NaN distances sort last."""
+    world, nq, kk = ids.shape
+    flat_ids = np.transpose(ids, (1, 0, 2)).reshape(nq, world * kk).astype(np.int64)
+    flat_d = np.transpose(dists, (1, 0, 2)).reshape(nq, world * kk).astype(np.float64)
+    empty = flat_ids < 0
+    key_d = np.where(empty | np.isnan(flat_d), np.inf, flat_d)
+    rank_last = (empty * 2 + (np.isnan(flat_d) & ~empty) * 1).astype(np.int64)       # real < NaN < empty
+    order = np.lexsort((-flat_ids, key_d, rank_last), axis=1)[:, :k] if nq else np.zeros((0, k), np.int64)
+    out_ids = np.take_along_axis(flat_ids, order, axis=1) if nq else np.zeros((0, k), np.int64)
+    out_d = np.take_along_axis(flat_d, order, axis=1) if nq else np.zeros((0, k))
+    if out_ids.shape[1] < k:
+        pad = k - out_ids.shape[1]
+        out_ids = np.concatenate([out_ids, np.full((nq, pad), -1, np.int64)], axis=1)
+        out_d = np.concatenate([out_d, np.full((nq, pad), np.inf)], axis=1)
+    counts = (out_ids >= 0).sum(axis=1).astype(np.int32)
+    return out_ids, np.where(out_ids >= 0, out_d, np.inf), counts
+
+
 class ShardedSearch(object):
     """index: the local shard (AnnoyIndex-shaped: get_nns_by_vector_batch,
     get_item_vectors).  Global id = offset[rank] + local id."""
@@ -76,6 +97,16 @@ class ShardedSearch(object):
         distances and counts on every rank."""
         ids, d, cnt = self.index.get_nns_by_vector_batch(Q, k, search_k)
         return self._gather_merge(ids, d, k)
+
+    def exact_search(self, Q, k):
+        """exact_search_nn (morna.py:681-716) over the row-sharded matrix: Q [nq, f] fp64, identical on
+        every rank; per-shard exact top-k (fp64, reference order), all-gather, merge with the bisect_left
+        tie rule.  Same ids and distances as one index holding all rows."""
+        ids, d, cnt = self.index.exact_search_batch(Q, k)
+        gids = np.where(ids >= 0, ids.astype(np.int64) + self.offsets[self.rank], -1)
+        all_ids = self._all_gather_np(gids)
+        all_d = self._all_gather_np(np.ascontiguousarray(d, np.float64))
+        return merge_topk_exact(all_ids, all_d, k)
 
     def get_nns_by_local_items(self, items, k, search_k=-1):
         """Each rank contributes the rows of some of its own items as queries

@@ -91,6 +91,60 @@ def test_sharded_search_two_ranks_gloo():
     assert dict(ret) == {0: "ok", 1: "ok"}
 
 
+class OracleExactShard(object):
+    """Shard whose exact search is the CPU oracle's restatement of exact_search_nn."""
+
+    def __init__(self, X):
+        self.X = np.asarray(X, np.float32)
+        self.f = self.X.shape[1]
+
+    def exact_search_batch(self, Q, k):
+        from oracle import capi
+        ids = np.full((len(Q), k), -1, np.int32)
+        d = np.full((len(Q), k), np.inf, np.float64)
+        cnt = np.zeros(len(Q), np.int32)
+        for i, q in enumerate(Q):
+            rid, rd = capi.exact_search(self.X, q, k)
+            ids[i, :len(rid)] = rid
+            d[i, :len(rid)] = rd
+            cnt[i] = len(rid)
+        return ids, d, cnt
+
+
+def _exact_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(99)
+        X = (rng.standard_normal((700, 16)) * (rng.random((700, 16)) < 0.5)).astype(np.float32)
+        X[650] = X[5]                     # exact ties across the shard boundary: higher id must come first
+        X[651] = X[5]
+        X[20] = X[5]
+        bounds = [0, 300, 700]
+        ss = ShardedSearch(OracleExactShard(X[bounds[rank]:bounds[rank + 1]]), rank, world, bounds[rank + 1] - bounds[rank])
+        Q = rng.standard_normal((5, 16))
+        Q[0] = X[5]
+        ids, d, cnt = ss.exact_search(Q, 12)
+        full = OracleExactShard(X).exact_search_batch(Q, 12)
+        assert ids.tolist() == full[0].astype(np.int64).tolist()
+        assert d.tobytes() == full[1].tobytes()
+        assert ids[0, :4].tolist() == [651, 650, 20, 5]
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_exact_search_two_ranks_gloo():
+    """Config 5's shape: exact search over a row-sharded matrix equals the single-index reference scan,
+    including the bisect_left tie order across shards."""
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_exact_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}
+
+
 def test_merge_topk_ties_and_padding():
     ids = np.array([[[5, 9, -1]], [[2, 7, 11]]], np.int64)          # [world=2, nq=1, k=3]
     d = np.array([[[0.1, 0.5, np.inf]], [[0.1, 0.2, 0.9]]], np.float32)
