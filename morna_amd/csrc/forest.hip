@@ -418,9 +418,9 @@ __global__ __launch_bounds__(SP_THREADS) void split_kernel(const float *__restri
 // the hyperplane of its node in every tree of the group.  L2 -> CU traffic per
 // (row, tree) drops from one row to 1/G row; same wave_dot order, same results.
 
-#define RW_THREADS 512    // 1024 caps the kernel at 128 VGPRs and spills the row buffers
+#define RW_THREADS 1024   // 16 waves: the kernel must stay within 128 VGPRs (one row buffer per wave)
 #define RW_WAVES (RW_THREADS / WAVE)
-#define RW_ROWS 256       // rows per window: the hyperplane staging is paid once per 32 rows of every wave
+#define RW_ROWS 256       // rows per window: the hyperplane staging is paid once per 16 rows of every wave
 #define RW_SLOTS 8        // hyperplanes resident in LDS (96 KB at D = 3000): one workgroup per CU
 
 // inverse of the permutation restricted to the tasks: row -> (task index, position in segment)
@@ -526,29 +526,14 @@ __global__ __launch_bounds__(RW_THREADS) void split_rw_kernel(
             }
         };
         auto valid = [&](int rr) { return rr < RW_ROWS && row_base + rr < n_items; };
-        // three row buffers in rotation: a row is requested two rows before it is used
-        float4 xa[NV], xb[NV], xc[NV];
-        int ma_a = -1, mp_a = 0, ma_b = -1, mp_b = 0, ma_c = -1, mp_c = 0;
-        int rr = w;
-        if (valid(rr)) {
-            load_row(rr, xa, ma_a, mp_a);
-            bool vb = valid(rr + RW_WAVES);
-            if (vb) load_row(rr + RW_WAVES, xb, ma_b, mp_b);
-            for (;;) {
-                const bool vc = vb && valid(rr + 2 * RW_WAVES);
-                if (vc) load_row(rr + 2 * RW_WAVES, xc, ma_c, mp_c);
-                process(xa, ma_a, mp_a);
-                if (!vb) break;
-                const bool va = vc && valid(rr + 3 * RW_WAVES);
-                if (va) load_row(rr + 3 * RW_WAVES, xa, ma_a, mp_a);
-                process(xb, ma_b, mp_b);
-                if (!vc) break;
-                vb = va && valid(rr + 4 * RW_WAVES);
-                if (vb) load_row(rr + 4 * RW_WAVES, xb, ma_b, mp_b);
-                process(xc, ma_c, mp_c);
-                if (!va) break;
-                rr += 3 * RW_WAVES;
-            }
+        // ONE row buffer per wave (<= 128 VGPRs), 16 waves per CU: the other three waves of the SIMD cover
+        // a wave's load latency.  Measured against two waves per SIMD with three row buffers in rotation
+        // (prefetch distance 2): 2.06 / 2.11 / 3.08 ms instead of 2.29 / 2.70 / 3.70 ms per level.
+        float4 xr[NV];
+        int ma = -1, mp = 0;
+        for (int rr = w; valid(rr); rr += RW_WAVES) {
+            load_row(rr, xr, ma, mp);
+            process(xr, ma, mp);
         }
     }
     __syncthreads();
