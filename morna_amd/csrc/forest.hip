@@ -400,6 +400,8 @@ __global__ __launch_bounds__(SP_THREADS) void split_kernel(const float *__restri
     int my_ones = 0;
     for (int r = w; r < nrows; r += SP_WAVES) {
         const float4 *x = (const float4 *)(X + (int64_t)items[r] * dpad);
+        // default cache policy on purpose: with non-temporal loads the rows are not kept in L2 for the
+        // other trees' chunks that follow on this XCD (measured: 8.7 ms instead of 4.9 ms per level)
         const float d = wave_dot(x, hs, nvec, lane);
         // Angular::side: dot != 0 ? dot > 0 : coin flip
         const int s = d != 0.f ? (d > 0.f) : pos_flip(nseed, (uint32_t)(pos0 + r));
