@@ -2,9 +2,15 @@
 
 Mirrors the reference's parser and dispatch (commanderson/morna
 morna.py:867-1054, 1338-1484): same subcommands, flag names, defaults and output
-format for the hot path.  Not carried over: `junctions`,
-the convergence back-off loop (-c / -ch), the metadata database (-m) and the
-junctions-by-sample shards (-b is accepted and ignored).
+format for the hot path, including the metadata join (-m) and the convergence
+back-off loop (-c / -ch, sam input only).  Not carried over:
+`junctions` and the junctions-by-sample shards (-b is accepted and ignored).
+
+One deliberate difference in the back-off loop: when the stream ends without
+convergence the reference's quiet branch prints the results of the LAST CHECKPOINT
+(morna.py:1452, a NameError if no checkpoint was reached) while its verbose branch
+finalises the whole query and searches again (morna.py:1421-1427); both branches
+here do the latter.
 
     python -m morna_amd.cli index --intropolis junctions.tsv.gz -x idx -s 9662 --n-trees 10
     python -m morna_amd.cli search -x idx -q 1234 -d
@@ -28,6 +34,14 @@ def add_search_parameters(subparser):
                            help='one of {sam, bed, raw}')
     subparser.add_argument('-d', '--distances', action='store_const', const=True, default=False,
                            help='include distances to nearest neighbors')
+    subparser.add_argument('-m', '--metadata', action='store_const', const=True, default=False,
+                           help='display results mapped to metadata')
+    subparser.add_argument('-c', '--convergence-backoff', metavar='<int>', type=int, required=False, default=None,
+                           help='attempt to converge on a solution with this backoff interval '
+                                '(check after c, then 2c, then 4c, and stop when no change)')
+    subparser.add_argument('-ch', '--checkpoint', metavar='<int>', type=int, required=False, default=0,
+                           help='do not start backoff until this point (check at checkpoint, '
+                                'then checkpoint + c, then continue exponential backoff)')
     subparser.add_argument('-q', '--query-id', metavar='<int>', type=int, required=False, default=None,
                            help='search for nearest neighbors to the sample already in the index with this sample id')
     subparser.add_argument('-e', '--exact', action='store_const', const=True, default=False,
@@ -60,6 +74,9 @@ def build_parser():
     index_parser.add_argument('-b', '--buffer-size', metavar='<int>', type=int, required=False, default=1024,
                               help='accepted for compatibility; the per-sample junction database is out of scope')
     index_parser.add_argument('-v', '--verbose', action='store_const', const=True, default=False, help='be talkative')
+    index_parser.add_argument('-m', '--metafile', metavar='<file>', type=str, required=False, default=None,
+                              help='path to metadata file with sample index in first column '
+                                   'and other keywords in other columns, whitespace delimited')
     index_parser.add_argument('--device', type=int, default=0, help='HIP device ordinal')
     index_parser.add_argument('--python-parse', action='store_const', const=True, default=False,
                               help='tokenise the intropolis file with the Python loop of the reference '
@@ -75,7 +92,7 @@ def main(argv=None, stdin=None, stdout=None):
     if args.subparser_name == 'index':
         from .index import go_index
         go_index(args.intropolis, args.basename, args.features, args.n_trees, args.sample_count,
-                 args.sample_threshold, args.buffer_size, args.verbose, None, device=args.device,
+                 args.sample_threshold, args.buffer_size, args.verbose, args.metafile, device=args.device,
                  native=not args.python_parse)
         return 0
     if args.subparser_name != 'search':
@@ -86,7 +103,7 @@ def main(argv=None, stdin=None, stdout=None):
     searcher = MornaSearch(basename=args.basename, device=args.device)
     if args.query_id is not None:                              # morna.py:1358-1365
         results = searcher.search_member_n(args.query_id, args.results, args.search_k,
-                                           include_distances=args.distances)
+                                           include_distances=args.distances, meta_db=args.metadata)
         results_output(results, stdout)
         return 0
     if args.format == "sam":
@@ -100,17 +117,49 @@ def main(argv=None, stdin=None, stdout=None):
         for junction in junction_generator:
             stdout.write(str(junction) + "\n")
         return 0
-    for i, junction in enumerate(junction_generator):          # morna.py:1455-1472
+    converge = bool(args.convergence_backoff) and args.format == 'sam'      # morna.py:1378
+    backoff = args.convergence_backoff
+    checkpoint = args.checkpoint
+    old_results = [-1 for _ in range(args.results)]
+    i = -1
+    for i, junction in enumerate(junction_generator):          # morna.py:1383-1472
         string_junction = " ".join(str(_) for _ in junction[:3])
         if args.verbose and i % 1000 == 0:
             sys.stderr.write(str(i) + " junctions into query sample\r")
+            sys.stderr.flush()
         if string_junction in searcher.sample_frequencies:
             searcher.update_query(junction)
+        if converge and i == checkpoint:
+            checkpoint += backoff
+            backoff += backoff
+            sys.stderr.write("\n")
+            searcher.finalize_query()
+            results = searcher.search_nn(args.results, args.search_k, include_distances=args.distances,
+                                         meta_db=args.metadata)
+            same = True
+            for j, result in enumerate(results[0]):
+                if not (result == old_results[j]):
+                    same = False
+            if same:
+                if args.verbose:
+                    sys.stderr.write("Converged after " + str(i) + " junctions.\n")
+                results_output(results, stdout)
+                return 0
+            if args.verbose:
+                sys.stderr.write("Not converged after " + str(i) + " junctions.\n")
+                sys.stderr.write("Old results:\n" + str(old_results) + "\n")
+                sys.stderr.write("New results:\n" + str(results[0]) + "\n")
+            old_results = results[0]
+    if converge and args.verbose:
+        sys.stderr.write("No convergence after " + str(i) + " junctions, but here's results:\n")
     searcher.finalize_query()
-    if args.exact:
-        results = searcher.exact_search_nn(args.results, include_distances=args.distances)
+    if args.verbose:
+        sys.stderr.write("\n")
+    if args.exact and not converge:
+        results = searcher.exact_search_nn(args.results, include_distances=args.distances, meta_db=args.metadata)
     else:
-        results = searcher.search_nn(args.results, args.search_k, include_distances=args.distances)
+        results = searcher.search_nn(args.results, args.search_k, include_distances=args.distances,
+                                     meta_db=args.metadata)
     results_output(results, stdout)
     return 0
 

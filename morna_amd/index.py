@@ -9,8 +9,8 @@ idf = log(sample_count / freq) (libm, so it is bit-identical to Python's).
 Everything per-nnz and everything numeric runs in libmorna_hip.so: junction
 lines are buffered as CSR arrays and handed over once by build().
 
-Out of scope here (SURVEY.md section 2, rows 10/11): the junctions-by-sample
-sqlite shards (update_junction_dbs) and the metadata database.
+Out of scope here (SURVEY.md section 2, row 10): the junctions-by-sample
+sqlite shards (update_junction_dbs).
 """
 import gzip
 import pickle
@@ -21,6 +21,7 @@ from math import log
 import numpy as np
 
 from .annoy import AnnoyIndex
+from .metadb import write_meta_db
 
 
 def count_samples(introp_file_handle, verbose=False):
@@ -135,6 +136,8 @@ class MornaIndex(AnnoyIndex):
             pickle.dump(dict(self.sample_frequencies), pickle_stream, 2)
         with open(basename + ".map.mor", 'wb') as pickle_stream:
             pickle.dump(self.internal_id_map, pickle_stream, 2)
+        if self.metafile:
+            write_meta_db(self.metafile, basename)      # morna.py:494-520
 
 
 def tokenize_line(line):

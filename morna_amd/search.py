@@ -7,8 +7,8 @@ shapes, same errors.  Query construction (a dict of summed coverages, then one
 hash + idf per distinct junction) stays in Python exactly as in the reference;
 the searches run in libmorna_hip.so.
 
-Out of scope: the metadata database join (`meta_db=True`, morna.py:666-676) --
-SURVEY.md section 2 row 7 -- asking for it raises NotImplementedError.
+`meta_db=True` appends the keywords of `<basename>.meta.mor` to the results
+(morna.py:666-676; metadb.py).
 """
 import pickle
 import sys
@@ -19,6 +19,7 @@ import numpy as np
 
 from . import _lib
 from .annoy import AnnoyIndex
+from .metadb import lookup_meta
 
 
 def results_output(results, out=None):
@@ -77,22 +78,25 @@ class MornaSearch(object):
             multiplier = (-1 if hash_value < 0 else 1)
             self.query_sample[hash_value % self.dim] += (multiplier * (self.query[junction] * idf_value))
 
-    def _no_meta(self, meta_db):
-        if meta_db:
-            raise NotImplementedError("the metadata database join (morna.py:666-676) is out of scope")
+    def _with_meta(self, results, meta_db):
+        """Append the metadata keywords of each result (morna.py:666-676)."""
+        if not meta_db:
+            return results
+        sample_ids = [self.inverse_lookup(internal_id) for internal_id in results[0]]
+        return results + (lookup_meta(self.basename, sample_ids),)
 
     def search_nn(self, num_neighbors, search_k, include_distances=True, meta_db=False):
         """Approximate neighbours of query_sample (morna.py:632-678)."""
-        self._no_meta(meta_db)
         if include_distances:
-            return self.annoy_index.get_nns_by_vector([feature for feature in self.query_sample],
-                                                      num_neighbors, search_k, include_distances)
-        return (self.annoy_index.get_nns_by_vector([feature for feature in self.query_sample],
-                                                   num_neighbors, search_k, include_distances),)
+            results = self.annoy_index.get_nns_by_vector([feature for feature in self.query_sample],
+                                                         num_neighbors, search_k, include_distances)
+        else:
+            results = (self.annoy_index.get_nns_by_vector([feature for feature in self.query_sample],
+                                                          num_neighbors, search_k, include_distances),)
+        return self._with_meta(results, meta_db)
 
     def exact_search_nn(self, num_neighbors, include_distances=True, meta_db=False):
         """Brute-force neighbours with cosine_distance (morna.py:681-730)."""
-        self._no_meta(meta_db)
         ids, d, cnt = self.annoy_index.exact_search_batch(np.array([self.query_sample], dtype=np.float64),
                                                           num_neighbors)
         m = int(cnt[0])
@@ -101,11 +105,10 @@ class MornaSearch(object):
         results = ([int(x) for x in ids[0, :m]],)
         if include_distances:
             results += ([float(x) for x in d[0, :m]],)
-        return results
+        return self._with_meta(results, meta_db)
 
     def search_member_n(self, query_id, num_neighbors, search_k, include_distances=True, meta_db=False):
         """Neighbours of an indexed sample (morna.py:733-787)."""
-        self._no_meta(meta_db)
         print("querying by sample id " + str(query_id))
         try:
             internal_id = self.internal_id_map[query_id]
@@ -116,5 +119,7 @@ class MornaSearch(object):
                              + "in the index.")
         print("this is internal id " + str(internal_id))
         if include_distances:
-            return self.annoy_index.get_nns_by_item(internal_id, num_neighbors, search_k, include_distances)
-        return (self.annoy_index.get_nns_by_item(internal_id, num_neighbors, search_k, include_distances),)
+            results = self.annoy_index.get_nns_by_item(internal_id, num_neighbors, search_k, include_distances)
+        else:
+            results = (self.annoy_index.get_nns_by_item(internal_id, num_neighbors, search_k, include_distances),)
+        return self._with_meta(results, meta_db)

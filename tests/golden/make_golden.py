@@ -102,6 +102,26 @@ EXPECTED = {
         [0, 1, 2, 3, 4, 5, 6]] * 7),
 }
 
+# morna.py:1128-1139 (metafile text) and 1221-1233 (test_metadata_indexing: search_member_n(1, 10, 100,
+# include_distances=False, meta_db=True) on the "simple" index) -- fetchone() tuples as lists
+META = [
+    '10\tSample 10\tThe 10th sample\n',
+    '1\tSample 1\tThe 1st sample\n',
+    '2\tSample 2\tThe 2nd sample\n',
+    '3\tSample 3\tThe 3rd sample\n',
+    '4\tSample 4\tThe 4th sample\n',
+    '5\tSample 5\tThe 5th sample\n',
+    '6\tSample 6\tThe 6th sample\n',
+    '7\tSample 7\tThe 7th sample\n',
+    '8\tSample 8\tThe 8th sample\n',
+    '9\tSample 9\tThe 9th sample\n',
+]
+META_EXPECTED = dict(query_sample_id=1, ids=[0, 2, 3, 1, 4, 5, 6, 7, 8, 9], keywords=[
+    ['Sample 1\tThe 1st sample\n'], ['Sample 3\tThe 3rd sample\n'], ['Sample 4\tThe 4th sample\n'],
+    ['Sample 2\tThe 2nd sample\n'], ['Sample 5\tThe 5th sample\n'], ['Sample 6\tThe 6th sample\n'],
+    ['Sample 7\tThe 7th sample\n'], ['Sample 8\tThe 8th sample\n'], ['Sample 9\tThe 9th sample\n'],
+    ['Sample 10\tThe 10th sample\n']])
+
 
 def main():
     with open(os.path.join(HERE, "morna_embedded_fixtures.json"), "w") as fh:
@@ -110,7 +130,7 @@ def main():
             note=("expected orderings were captured by the reference authors at a collision-free "
                   "feature dimension (3000); rows containing exact distance ties are pinned only "
                   "up to tie order (SURVEY.md section 4)"),
-            generic=GENERIC, lossy=LOSSY, expected=EXPECTED,
+            generic=GENERIC, lossy=LOSSY, expected=EXPECTED, meta=META, meta_expected=META_EXPECTED,
             sample_count_expected=10), fh, indent=1)
 
     ref_tiny = "/root/reference/tests/tiny_intropolis.tsv"

@@ -114,3 +114,104 @@ def test_cli_index_and_stream_search(tmp_path, embedded):
     out = io.StringIO()
     assert cli.main(["search", "-x", base, "-q", "3", "-r", "2", "-d"], stdout=out) == 0
     assert out.getvalue().split("\n")[0].split("\t")[1] == str(ref_idx.internal_id_map[3])
+
+
+def test_metadata_indexing(tmp_path, embedded, capsys):
+    """morna.py:1195-1240 test_metadata_indexing: go_index with a metafile, then
+    search_member_n(1, 10, 100, include_distances=False, meta_db=True) -> (ids, fetchone() tuples)."""
+    from morna_amd.index import go_index
+    from morna_amd.search import MornaSearch
+    from morna_amd import cli
+    src, meta = str(tmp_path / "junctions.temp"), str(tmp_path / "meta.temp")
+    _write_gz(src, embedded["generic"])
+    with open(meta, "w") as fh:
+        fh.write("".join(embedded["meta"]))
+    base = str(tmp_path / "tempIndex")
+    go_index(intropolis=src, basename=base, features=3000, n_trees=20, sample_count=10, sample_threshold=1,
+             buffer_size=1024, verbose=False, metafile=meta)
+    assert os.path.exists(base + ".meta.mor")
+    exp = embedded["meta_expected"]
+    s = MornaSearch(basename=base)
+    results = s.search_member_n(exp["query_sample_id"], 10, 100, include_distances=False, meta_db=True)
+    assert results == (exp["ids"], [tuple(k) for k in exp["keywords"]])
+    ids, d, kw = s.search_member_n(exp["query_sample_id"], 10, 100, include_distances=True, meta_db=True)
+    assert ids == exp["ids"] and kw == [tuple(k) for k in exp["keywords"]] and len(d) == 10
+    s.query_sample = [float(x) for x in s.annoy_index.get_item_vector(0)]
+    assert s.exact_search_nn(3, include_distances=False, meta_db=True)[1][0] == tuple(exp["keywords"][0])
+    assert s.search_nn(3, 100, include_distances=False, meta_db=True)[1][0] == tuple(exp["keywords"][0])
+    # the command line: index -m <file>, search -m
+    base2 = str(tmp_path / "cliIndex")
+    assert cli.main(["index", "--intropolis", src, "-x", base2, "--features", "3000", "--n-trees", "20", "-s", "10",
+                     "-t", "1", "-m", meta]) == 0
+    out = io.StringIO()
+    assert cli.main(["search", "-x", base2, "-q", "1", "-r", "10", "-m"], stdout=out) == 0
+    rows = [ln.split("\t", 2) for ln in out.getvalue().rstrip("\n").split("\n")]
+    assert [int(r[1]) for r in rows] == exp["ids"]
+    assert rows[0][2] == str(tuple(exp["keywords"][0]))               # results_output prints str(fetchone())
+
+
+def _sam_lines(junctions):
+    """One spliced alignment per (chrom, start, end) repeated cov times (utils.py:194-241 coordinates)."""
+    out = []
+    for chrom, start, end, cov in junctions:
+        for _ in range(cov):
+            out.append("r\t0\t%s\t%d\t255\t10M%dN10M\t*\t0\t0\t*\t*\n" % (chrom, start - 10, end - start + 1))
+    return out
+
+
+def test_cli_convergence_backoff(tmp_path, embedded):
+    """-c / -ch (morna.py:1378-1452): search at junction checkpoint, checkpoint + c, + 2c, ...; stop when the
+    result ids repeat; at stream end without convergence search the whole query."""
+    from morna_amd import cli, streams
+    from oracle import morna_ref
+    src = str(tmp_path / "j.gz")
+    _write_gz(src, embedded["generic"])
+    base = str(tmp_path / "idx")
+    assert cli.main(["index", "--intropolis", src, "-x", base, "--features", "3000", "--n-trees", "10", "-s", "10",
+                     "-t", "1"]) == 0
+    juncs = []
+    for ln in embedded["generic"]:
+        key, samples, cov = morna_ref.tokenize_line(ln)
+        if 8 in samples:
+            c, a, b = key.split(" ")
+            juncs.append((c, int(a), int(b), cov[samples.index(8)]))
+    sam = _sam_lines(juncs)
+    parsed = list(streams.junctions_from_sam_stream(io.StringIO("".join(sam))))
+    total = {}
+    for j in parsed:
+        total[tuple(j[:3])] = total.get(tuple(j[:3]), 0) + j[3]
+    assert total == {(c, a, b): cov for c, a, b, cov in juncs}
+
+    def run(extra):
+        out = io.StringIO()
+        assert cli.main(["search", "-x", base, "-f", "sam", "-r", "3"] + extra, stdin=io.StringIO("".join(sam)),
+                        stdout=out) == 0
+        return [int(ln.split("\t")[1]) for ln in out.getvalue().strip().split("\n")]
+    full = run([])
+    assert full[0] == 7                                                # sample 8 is internal id 7
+    # expected: replay the loop through the MornaSearch methods on prefixes of the junction stream (the
+    # zero-overlap samples tie at sqrt(2), so the replay must break ties as the searched index does)
+    from morna_amd.search import MornaSearch
+
+    def ref_search(prefix):
+        rs = MornaSearch(basename=base)
+        for j in prefix:
+            rs.update_query(j)
+        rs.finalize_query()
+        return rs.search_nn(3, 100, include_distances=False)[0]
+    assert ref_search(parsed) == full
+    for c, ch in ((1, 0), (2, 1), (1000, 0), (1000, 5000)):
+        backoff, checkpoint, old, want = c, ch, [-1, -1, -1], None
+        for i in range(len(parsed)):
+            if i == checkpoint:
+                checkpoint += backoff
+                backoff += backoff
+                res = ref_search(parsed[:i + 1])
+                if res == old:
+                    want = res
+                    break
+                old = res
+        if want is None:
+            want = ref_search(parsed)
+        got = run(["-c", str(c), "-ch", str(ch)])
+        assert got == want, (c, ch, got, want)

@@ -97,6 +97,28 @@ def test_cli_parser_defaults_match_reference():
         ("morna", 3000, 200, None, 100, 1024)                         # morna.py:970-1021
     s = p.parse_args(["search", "-x", "idx"])
     assert (s.search_k, s.format, s.distances, s.query_id, s.exact, s.results) == (100, "sam", False, None, False, 20)
+    assert (s.metadata, s.convergence_backoff, s.checkpoint, a.metafile) == (False, None, 0, None)   # morna.py:907-924, 1016
+
+
+def test_metadata_db_roundtrip(tmp_path, embedded):
+    """<basename>.meta.mor: the table MornaIndex.save writes and the fetchone() tuples the
+    searches append (morna.py:494-520, 666-676); sample ids in the order test_metadata_indexing expects."""
+    from morna_amd.metadb import lookup_meta, write_meta_db
+    meta = str(tmp_path / "meta.tsv")
+    with open(meta, "w") as fh:
+        fh.write("".join(embedded["meta"]))
+    base = str(tmp_path / "idx")
+    write_meta_db(meta, base)
+    write_meta_db(meta, base)                                         # overwriting an old index drops the table first
+    exp = embedded["meta_expected"]
+    sample_ids = [i + 1 for i in exp["ids"]]                          # "simple": internal id i <-> sample id i + 1
+    got = lookup_meta(base, sample_ids)
+    assert got == [tuple(k) for k in exp["keywords"]]
+    assert lookup_meta(base, [4242, None]) == [None, None]            # unknown sample: fetchone() -> None
+    with open(meta, "w") as fh:
+        fh.write("77\n")
+    with pytest.raises(IndexError):                                   # id with no keywords, as line.split(None,1)[1]
+        write_meta_db(meta, str(tmp_path / "bad"))
 
 
 # ---- native pre-pass (morna_parse_intropolis): no GPU involved -------------------------------
