@@ -92,6 +92,15 @@ int morna_lines_arrays(const morna_lines *L, const uint8_t **key_bytes, const in
                        const int64_t **ext_ids);
 int morna_lines_freq_entry(const morna_lines *L, int64_t i, const char **key, int64_t *key_len, int64_t *freq);
 int morna_stage_lines(morna_index *h, const morna_lines *L);
+/*
+ * Binary pre-tokenised cache of a parse: what go_index's line loop
+ * (morna.py:841-861) would recompute on every run over the same file.  tag[4] is the
+ * caller's identity of the source (size, mtime, sample_count argument, threshold); load
+ * hands it back so the caller can decide whether the cache is still valid.  MORNA_E_IO when
+ * the file is missing, truncated or not such a cache.
+ */
+int morna_lines_save(const morna_lines *L, const char *path, const int64_t *tag);
+int morna_lines_load(const char *path, int64_t *tag_out, morna_lines **out);
 int morna_lines_free(morna_lines *L);
 
 /* AnnoyIndex.get_n_items()                                     morna.py:1174 */

@@ -42,6 +42,8 @@ SIGNATURES = {
     "morna_lines_arrays": (C.c_int, [_p] + [C.POINTER(_p)] * 7),
     "morna_lines_freq_entry": (C.c_int, [_p, _i64, C.POINTER(C.c_char_p), C.POINTER(_i64), C.POINTER(_i64)]),
     "morna_stage_lines": (C.c_int, [_p, _p]),
+    "morna_lines_save": (C.c_int, [_p, C.c_char_p, _p]),
+    "morna_lines_load": (C.c_int, [C.c_char_p, _p, C.POINTER(_p)]),
     "morna_lines_free": (C.c_int, [_p]),
     "morna_get_n_items": (_i64, [_p]),
     "morna_get_item_vector": (C.c_int, [_p, _i32, _p]),

@@ -81,6 +81,9 @@ def build_parser():
     index_parser.add_argument('--python-parse', action='store_const', const=True, default=False,
                               help='tokenise the intropolis file with the Python loop of the reference '
                                    'instead of the native pre-pass (same index either way)')
+    index_parser.add_argument('--cache', metavar='<file>', type=str, required=False, default=None,
+                              help='binary pre-tokenised cache of the intropolis file: reused when it matches the '
+                                   'file, sample count and threshold, (re)written otherwise')
     add_search_parameters(search_parser)
     return parser
 
@@ -93,7 +96,7 @@ def main(argv=None, stdin=None, stdout=None):
         from .index import go_index
         go_index(args.intropolis, args.basename, args.features, args.n_trees, args.sample_count,
                  args.sample_threshold, args.buffer_size, args.verbose, args.metafile, device=args.device,
-                 native=not args.python_parse)
+                 native=not args.python_parse, cache=args.cache)
         return 0
     if args.subparser_name != 'search':
         build_parser().print_help()

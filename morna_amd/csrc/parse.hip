@@ -109,6 +109,21 @@ inline void split_tabs(const std::string &s, size_t b, size_t e, std::vector<std
         }
 }
 
+const char LINES_MAGIC[8] = {'M', 'O', 'R', 'N', 'A', 'L', 'N', '1'};   // cache blob, see morna_lines_save
+
+template <typename T>
+bool put_vec(FILE *f, const std::vector<T> &v)
+{
+    return v.empty() || fwrite(v.data(), sizeof(T), v.size(), f) == v.size();
+}
+template <typename T>
+bool get_vec(FILE *f, std::vector<T> &v, int64_t n)
+{
+    if (n < 0) return false;
+    v.resize((size_t)n);
+    return n == 0 || fread(v.data(), sizeof(T), (size_t)n, f) == (size_t)n;
+}
+
 }  // namespace
 
 extern "C" {
@@ -271,6 +286,106 @@ int morna_lines_freq_entry(const morna_lines *L, int64_t i, const char **key, in
     *key = L->freq_keys[(size_t)i].data();
     *key_len = (int64_t)L->freq_keys[(size_t)i].size();
     *freq = L->freq_vals[(size_t)i];
+    return MORNA_OK;
+}
+
+// ---- binary pre-tokenised cache: the parsed arrays as one little-endian blob, so
+// that a second `index` run over the same file (other n_trees / features / seed) skips inflate + tokenising.
+//   "MORNALN1", tag[4] (caller's identity of the source: size, mtime, sample_count argument, threshold),
+//   counts[8] as morna_lines_counts, then key_bytes, key_off, row_ptr, item_ids, cov, idf, ext_ids,
+//   freq_vals, freq key lengths (int64 each), freq key bytes.
+int morna_lines_save(const morna_lines *L, const char *path, const int64_t *tag)
+{
+    if (!L || !path || !tag) {
+        set_error("lines_save: null argument");
+        return MORNA_E_INVALID;
+    }
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+        set_error("Unable to open %s for writing", path);
+        return MORNA_E_IO;
+    }
+    int64_t counts[8];
+    morna_lines_counts(L, counts);
+    std::vector<int64_t> klen;
+    std::vector<uint8_t> kbytes;
+    for (const std::string &k : L->freq_keys) {
+        klen.push_back((int64_t)k.size());
+        kbytes.insert(kbytes.end(), k.begin(), k.end());
+    }
+    const int64_t kb = (int64_t)kbytes.size();
+    bool ok = fwrite(LINES_MAGIC, 1, 8, f) == 8 && fwrite(tag, 8, 4, f) == 4 && fwrite(counts, 8, 8, f) == 8 &&
+              fwrite(&kb, 8, 1, f) == 1 && put_vec(f, L->key_bytes) && put_vec(f, L->key_off) &&
+              put_vec(f, L->row_ptr) && put_vec(f, L->item_ids) && put_vec(f, L->cov) && put_vec(f, L->idf) &&
+              put_vec(f, L->ext_ids) && put_vec(f, L->freq_vals) && put_vec(f, klen) && put_vec(f, kbytes);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) {
+        set_error("short write to %s", path);
+        return MORNA_E_IO;
+    }
+    return MORNA_OK;
+}
+
+int morna_lines_load(const char *path, int64_t *tag_out, morna_lines **out)
+{
+    if (!path || !tag_out || !out) {
+        set_error("lines_load: null argument");
+        return MORNA_E_INVALID;
+    }
+    *out = nullptr;
+    FILE *f = fopen(path, "rb");
+    if (!f) {
+        set_error("Unable to open %s", path);
+        return MORNA_E_IO;
+    }
+    char magic[8];
+    int64_t counts[8], kb = 0;
+    morna_lines *L = new morna_lines();
+    std::vector<int64_t> klen;
+    std::vector<uint8_t> kbytes;
+    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, LINES_MAGIC, 8) == 0 && fread(tag_out, 8, 4, f) == 4 &&
+              fread(counts, 8, 8, f) == 8 && fread(&kb, 8, 1, f) == 1;
+    if (ok) {
+        // the counts must account for the file's size exactly before anything is allocated from them
+        for (int i = 0; i < 8; i++) ok = ok && counts[i] >= 0 && counts[i] < ((int64_t)1 << 56);
+        ok = ok && kb >= 0 && kb < ((int64_t)1 << 56);
+        const long here = ftell(f);
+        ok = ok && fseek(f, 0, SEEK_END) == 0;
+        const long size = ftell(f);
+        ok = ok && fseek(f, here, SEEK_SET) == 0;
+        const double want = (double)here + (double)counts[5] + 16.0 * (double)(counts[0] + 1) + 8.0 * (double)counts[1] +
+                            8.0 * (double)counts[0] + 8.0 * (double)counts[2] + 16.0 * (double)counts[6] + (double)kb;
+        ok = ok && (double)size == want;
+    }
+    ok = ok && get_vec(f, L->key_bytes, counts[5]) && get_vec(f, L->key_off, counts[0] + 1) &&
+         get_vec(f, L->row_ptr, counts[0] + 1) && get_vec(f, L->item_ids, counts[1]) && get_vec(f, L->cov, counts[1]) &&
+         get_vec(f, L->idf, counts[0]) && get_vec(f, L->ext_ids, counts[2]) && get_vec(f, L->freq_vals, counts[6]) &&
+         get_vec(f, klen, counts[6]) && get_vec(f, kbytes, kb);
+    // nothing may follow, and the offsets must describe the arrays that were read
+    ok = ok && fgetc(f) == EOF && L->key_off.front() == 0 && L->key_off.back() == counts[5] &&
+         L->row_ptr.front() == 0 && L->row_ptr.back() == counts[1];
+    fclose(f);
+    if (ok) {
+        int64_t pos = 0;
+        for (int64_t i = 0; ok && i < counts[6]; i++) {
+            ok = klen[(size_t)i] >= 0 && pos + klen[(size_t)i] <= kb;
+            if (ok) L->freq_keys.emplace_back((const char *)kbytes.data() + pos, (size_t)klen[(size_t)i]);
+            pos += klen[(size_t)i];
+        }
+        ok = ok && pos == kb;
+    }
+    for (int64_t i = 0; ok && i < counts[0]; i++)
+        ok = L->key_off[(size_t)i] <= L->key_off[(size_t)i + 1] && L->row_ptr[(size_t)i] <= L->row_ptr[(size_t)i + 1];
+    for (int64_t i = 0; ok && i < counts[1]; i++) ok = L->item_ids[(size_t)i] >= 0 && L->item_ids[(size_t)i] < counts[2];
+    if (!ok) {
+        delete L;
+        set_error("%s is not a pre-tokenised intropolis cache (or is truncated)", path);
+        return MORNA_E_IO;
+    }
+    L->skipped = counts[3];
+    L->sample_count = counts[4];
+    L->lines_read = counts[7];
+    *out = L;
     return MORNA_OK;
 }
 

@@ -152,12 +152,32 @@ class ParsedLines(object):
     """Result of the native pre-pass (morna_parse_intropolis): the kept junction
     lines of an intropolis file as the arrays the C ABI stages, owned by the library."""
 
-    def __init__(self, path, sample_count=None, sample_threshold=100):
+    def __init__(self, path, sample_count=None, sample_threshold=100, cache=None):
+        """cache: path of the binary pre-tokenised cache.  It is used when it was written from this very
+        file (same size and mtime) with the same sample_count argument and threshold; otherwise the
+        file is parsed and the cache (re)written."""
         import ctypes as C
+        import os
         from ._lib import check, lib
         self._p = C.c_void_p()
-        check(lib().morna_parse_intropolis(str(path).encode(), int(sample_count or 0), int(sample_threshold),
-                                           C.byref(self._p)))
+        self.from_cache = False
+        tag = None
+        if cache:
+            st = os.stat(path)
+            tag = np.array([st.st_size, st.st_mtime_ns, int(sample_count or 0), int(sample_threshold)], np.int64)
+            if os.path.exists(cache):
+                got = np.zeros(4, np.int64)
+                rc = lib().morna_lines_load(str(cache).encode(), got.ctypes.data_as(C.c_void_p), C.byref(self._p))
+                if rc == 0 and (got == tag).all():
+                    self.from_cache = True
+                elif rc == 0:                                  # a cache of some other file or other parameters
+                    lib().morna_lines_free(self._p)
+                    self._p = C.c_void_p()
+        if not self.from_cache:
+            check(lib().morna_parse_intropolis(str(path).encode(), int(sample_count or 0), int(sample_threshold),
+                                               C.byref(self._p)))
+            if cache:
+                check(lib().morna_lines_save(self._p, str(cache).encode(), tag.ctypes.data_as(C.c_void_p)))
         counts = np.zeros(8, np.int64)
         check(lib().morna_lines_counts(self._p, counts.ctypes.data_as(C.c_void_p)))
         (self.n_lines, self.nnz, self.n_items, self.skipped, self.sample_count, self.key_bytes_n,
@@ -204,10 +224,11 @@ class ParsedLines(object):
 
 
 def go_index_native(intropolis, basename, features, n_trees, sample_count, sample_threshold, buffer_size, verbose,
-                    metafile, device=0, save=True, seed=0):
+                    metafile, device=0, save=True, seed=0, cache=None):
     """go_index with the tokenising loop done by the library (morna_parse_intropolis)
-    instead of the Python interpreter; same index, same files."""
-    parsed = ParsedLines(intropolis, sample_count, sample_threshold)
+    instead of the Python interpreter; same index, same files.  `cache`: binary
+    pre-tokenised cache file to reuse / write (ParsedLines)."""
+    parsed = ParsedLines(intropolis, sample_count, sample_threshold, cache=cache)
     if verbose:
         print('\nThere are {} samples.'.format(parsed.sample_count))
     morna_index = MornaIndex(parsed.sample_count, basename, dim=features, sample_threshold=sample_threshold,
@@ -231,11 +252,11 @@ def go_index_native(intropolis, basename, features, n_trees, sample_count, sampl
 
 
 def go_index(intropolis, basename, features, n_trees, sample_count, sample_threshold, buffer_size, verbose,
-             metafile, device=0, save=True, seed=0, native=False):
+             metafile, device=0, save=True, seed=0, native=False, cache=None):
     """`morna index` (morna.py:824-865): gzipped intropolis file -> index files."""
-    if native:
+    if native or cache:
         return go_index_native(intropolis, basename, features, n_trees, sample_count, sample_threshold, buffer_size,
-                               verbose, metafile, device=device, save=save, seed=seed)
+                               verbose, metafile, device=device, save=save, seed=seed, cache=cache)
     if not sample_count:
         with gzip.open(intropolis, "rt") as introp_file_handle:
             sample_count = count_samples(introp_file_handle, verbose)

@@ -215,3 +215,22 @@ def test_cli_convergence_backoff(tmp_path, embedded):
             want = ref_search(parsed)
         got = run(["-c", str(c), "-ch", str(ch)])
         assert got == want, (c, ch, got, want)
+
+
+def test_cli_index_from_pretokenised_cache(tmp_path, embedded):
+    """`index --cache`: the second run builds from the cache alone and yields the same index files."""
+    from morna_amd import cli
+    from morna_amd.search import MornaSearch
+    src = str(tmp_path / "j.gz")
+    _write_gz(src, embedded["generic"])
+    cache = str(tmp_path / "j.cache")
+    common = ["index", "--intropolis", src, "--features", "128", "--n-trees", "6", "-t", "1"]
+    assert cli.main(common + ["-x", str(tmp_path / "plain")]) == 0
+    assert cli.main(common + ["-x", str(tmp_path / "c1"), "--cache", cache]) == 0
+    stamp = os.stat(cache).st_mtime_ns
+    assert cli.main(common + ["-x", str(tmp_path / "c2"), "--cache", cache]) == 0
+    assert os.stat(cache).st_mtime_ns == stamp                         # reused, not rewritten
+    for ext in (".annoy.mor", ".stats.mor", ".freq.mor", ".map.mor"):
+        blobs = [open(str(tmp_path / b) + ext, "rb").read() for b in ("plain", "c1", "c2")]
+        assert blobs[0] == blobs[1] == blobs[2], ext
+    assert MornaSearch(str(tmp_path / "c2")).search_member_n(3, 4, 100)[0][0] == 2

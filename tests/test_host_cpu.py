@@ -175,3 +175,39 @@ def test_native_parser_tiny_intropolis_and_errors(tmp_path):
     _write(p, ["chr1\t1\t2\t+\tGT\tAG\t7,x\t1,1\n"], False)
     with pytest.raises(ValueError):
         mindex.ParsedLines(p, 5, 1)
+
+
+def test_pretokenised_cache_roundtrip_and_invalidation(tmp_path, embedded):
+    """the binary cache holds exactly what the parse produced; it is reused only for the
+    same file (size, mtime), sample_count argument and threshold; damaged files are refused."""
+    import os
+    src = str(tmp_path / "j.tsv.gz")
+    _write(src, embedded["lossy"], True)
+    cache = str(tmp_path / "j.cache")
+    first = mindex.ParsedLines(src, 10, 4, cache=cache)
+    assert not first.from_cache and os.path.exists(cache)
+    again = mindex.ParsedLines(src, 10, 4, cache=cache)
+    assert again.from_cache
+    plain = mindex.ParsedLines(src, 10, 4)
+    for k in ("n_lines", "nnz", "n_items", "skipped", "sample_count", "key_bytes_n", "n_keys", "lines_read"):
+        assert getattr(again, k) == getattr(plain, k), k
+    a, b = again.arrays(), plain.arrays()
+    for k in a:
+        assert a[k].tobytes() == b[k].tobytes(), k
+    assert again.frequencies() == plain.frequencies()
+    # other threshold / sample_count argument / touched source: parsed again, cache rewritten
+    assert not mindex.ParsedLines(src, 10, 6, cache=cache).from_cache
+    assert mindex.ParsedLines(src, 10, 6, cache=cache).from_cache
+    assert not mindex.ParsedLines(src, None, 6, cache=cache).from_cache
+    st = os.stat(src)
+    os.utime(src, ns=(st.st_atime_ns, st.st_mtime_ns + 10**9))
+    assert not mindex.ParsedLines(src, None, 6, cache=cache).from_cache
+    assert mindex.ParsedLines(src, None, 6, cache=cache).from_cache
+    # truncated or foreign files are not trusted: parse again and overwrite
+    blob = open(cache, "rb").read()
+    for bad in (blob[:len(blob) // 2], b"not a cache", blob + b"x"):
+        with open(cache, "wb") as fh:
+            fh.write(bad)
+        got = mindex.ParsedLines(src, None, 6, cache=cache)
+        assert not got.from_cache and got.n_items == 7
+        assert open(cache, "rb").read() == blob
