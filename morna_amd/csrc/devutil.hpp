@@ -162,6 +162,63 @@ __device__ inline float wave_sum_lane0(float v)
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 
+// GT wave sums at once, each with exactly the additions of wave_sum_lane0 (same pairs at every
+// stage; an addition may have its operands swapped, which is exact).  At stage 32 two values share
+// one v_permlane32_swap (the lower half of the wave goes on with one value, the upper half with the
+// other), at stage 16 two registers share one v_permlane16_swap, at stage 8 two registers share a
+// pair of DPP shifts: 8 values cost 18 VALU operations instead of 8 x 12, and no chain waits for
+// another.  Value j ends in lane j * (64 / GT); the other lanes hold partial sums.
+template <int CTRL>
+__device__ inline float dpp_move(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ inline float swap32_add(float a, float b)
+{
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    // r[0] = {a.lo, b.lo}, r[1] = {a.hi, b.hi}: lanes 0-31 add a's halves, lanes 32-63 b's
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ inline float swap16_add(float a, float b)
+{
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    // r[0] = rows {a0, b0, a2, b2}, r[1] = rows {a1, b1, a3, b3}
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int GT>
+__device__ inline float wave_sum_multi(const float (&v)[GT], int lane)
+{
+    static_assert(GT == 2 || GT == 3 || GT == 4 || GT == 8, "wave_sum_multi: 2, 3, 4 or 8 values");
+    float u;
+    if constexpr (GT == 3) {   // as four values with a zero in the fourth place: value j ends in lane 16 j
+        const float v4[4] = {v[0], v[1], v[2], 0.f};
+        return wave_sum_multi<4>(v4, lane);
+    }
+    if constexpr (GT == 8) {
+        const float s0 = swap32_add(v[0], v[4]), s1 = swap32_add(v[1], v[5]);
+        const float s2 = swap32_add(v[2], v[6]), s3 = swap32_add(v[3], v[7]);
+        const float t0 = swap16_add(s0, s2);   // rows: v0, v2, v4, v6
+        const float t1 = swap16_add(s1, s3);   // rows: v1, v3, v5, v7
+        const float x = t0 + dpp_move<0x108>(t0);   // row_shl:8 -- lanes 0-7 of a row: t0[l] + t0[l + 8]
+        const float y = dpp_move<0x118>(t1) + t1;   // row_shr:8 -- lanes 8-15 of a row: t1[l - 8] + t1[l]
+        u = (lane & 8) ? y : x;                     // 8-lane groups: v0, v1, v2, ... v7
+    } else if constexpr (GT == 4) {
+        const float s0 = swap32_add(v[0], v[2]), s1 = swap32_add(v[1], v[3]);
+        u = swap16_add(s0, s1);                     // rows: v0, v1, v2, v3
+        u = u + dpp_move<0x108>(u);
+    } else {
+        u = swap32_add(v[0], v[1]);                 // halves: v0, v1
+        u = swap16_add(u, u);                       // rows 0 / 2: u[l] + u[l + 16]
+        u = u + dpp_move<0x108>(u);
+    }
+    u = u + dpp_move<0x104>(u);
+    u = u + dpp_move<0x102>(u);
+    u = u + dpp_move<0x101>(u);
+    return u;
+}
+
 // fold of the four per-lane chains, then the butterfly (lane 0's value, broadcast)
 __device__ inline float wave_dot_finish(float a0, float a1, float a2, float a3)
 {

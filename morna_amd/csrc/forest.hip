@@ -398,15 +398,40 @@ __global__ __launch_bounds__(SP_THREADS) void split_kernel(const float *__restri
     uint8_t *sd = side + (int64_t)t.tree * n_items + t.start + pos0;
     const uint32_t nseed = node_seed(seed, (uint32_t)t.tree, (uint32_t)t.level, (uint32_t)t.start, (uint32_t)t.attempt);
     int my_ones = 0;
-    for (int r = w; r < nrows; r += SP_WAVES) {
-        const float4 *x = (const float4 *)(X + (int64_t)items[r] * dpad);
-        // default cache policy on purpose: with non-temporal loads the rows are not kept in L2 for the
-        // other trees' chunks that follow on this XCD (measured: 8.7 ms instead of 4.9 ms per level)
-        const float d = wave_dot(x, hs, nvec, lane);
-        // Angular::side: dot != 0 ? dot > 0 : coin flip
-        const int s = d != 0.f ? (d > 0.f) : pos_flip(nseed, (uint32_t)(pos0 + r));
-        if (lane == 0) sd[r] = (uint8_t)s;
-        my_ones += s;
+    // A wave takes FOUR rows at a time: one LDS read of the hyperplane serves four rows, four row
+    // streams are in flight, and the four lane-sums are reduced together (wave_sum_multi: row j's dot
+    // arrives in lane 16 j, which writes its side).  Same chains per row as wave_dot.
+    // Default cache policy on purpose: with non-temporal loads the rows are not kept in L2 for the
+    // other trees' chunks that follow on this XCD (measured: 8.7 ms instead of 4.9 ms per level).
+    for (int r = 4 * w; r < nrows; r += 4 * SP_WAVES) {
+        const float4 *x[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int rj = r + j < nrows ? r + j : r;   // a missing row repeats row r; its result is dropped
+            x[j] = (const float4 *)(X + (int64_t)items[rj] * dpad);
+        }
+        Acc4 c[4] = {acc4_zero(), acc4_zero(), acc4_zero(), acc4_zero()};
+#pragma unroll 2
+        for (int i = lane; i < nvec; i += WAVE) {   // nvec is a multiple of 64: no lane idles
+            const float4 x0 = x[0][i], x1 = x[1][i], x2 = x[2][i], x3 = x[3][i];
+            const float4 hv = hs[i];
+            fma4(c[0], x0, hv);
+            fma4(c[1], x1, hv);
+            fma4(c[2], x2, hv);
+            fma4(c[3], x3, hv);
+        }
+        float f[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) f[j] = (c[j].lo.x + c[j].lo.y) + (c[j].hi.x + c[j].hi.y);
+        const float d = wave_sum_multi<4>(f, lane);
+        const int rr = r + (lane >> 4);
+        int s = 0;
+        if ((lane & 15) == 0 && rr < nrows) {
+            // Angular::side: dot != 0 ? dot > 0 : coin flip
+            s = d != 0.f ? (d > 0.f) : pos_flip(nseed, (uint32_t)(pos0 + rr));
+            sd[rr] = (uint8_t)s;
+        }
+        my_ones += __builtin_popcountll(__ballot(s));
     }
     if (lane == 0 && my_ones) atomicAdd(&s_ones, my_ones);
     __syncthreads();
@@ -423,7 +448,7 @@ __global__ __launch_bounds__(SP_THREADS) void split_kernel(const float *__restri
 #define RW_THREADS 1024   // 16 waves: the kernel must stay within 128 VGPRs (one row buffer per wave)
 #define RW_WAVES (RW_THREADS / WAVE)
 #define RW_ROWS 256       // rows per window: the hyperplane staging is paid once per 16 rows of every wave
-#define RW_SLOTS 8        // hyperplanes resident in LDS (96 KB at D = 3000): one workgroup per CU
+#define RW_SLOTS 12       // hyperplanes resident in LDS (144 KB at D = 3000): one workgroup per CU
 
 // inverse of the permutation restricted to the tasks: row -> (task index, position in segment)
 __global__ void invert_kernel(const SplitTask *__restrict__ tasks, const int2 *__restrict__ info /* task per chunk */,
@@ -479,6 +504,7 @@ __global__ __launch_bounds__(RW_THREADS) void split_rw_kernel(
     }
     __syncthreads();
     if (nslots > 0) {
+        constexpr int LSTEP = WAVE / (GT == 3 ? 4 : GT);
         const int ng = t1 - t0;
         const int64_t row_base = (int64_t)win * RW_ROWS;
         // a row and its (task, position) per tree of the group are fetched one row ahead
@@ -489,23 +515,23 @@ __global__ __launch_bounds__(RW_THREADS) void split_rw_kernel(
             for (int k = 0; k < NV; k++) xr[k] = xp[lane + k * WAVE];   // dpad == NV * 256: no idle lane
             ma = -1;
             mp = 0;
-            if (lane < ng) {
-                ma = row_task[(int64_t)(t0 + lane) * n_items + row];
-                mp = row_pos[(int64_t)(t0 + lane) * n_items + row];
+            if (lane % LSTEP == 0 && lane / LSTEP < ng) {   // lane gi * LSTEP looks after tree gi of the group
+                ma = row_task[(int64_t)(t0 + lane / LSTEP) * n_items + row];
+                mp = row_pos[(int64_t)(t0 + lane / LSTEP) * n_items + row];
             }
         };
         // the row against its node's hyperplane in every tree of the group, branch-free and with k
-        // outermost: GT independent FMA chains and reductions are in flight, a tree that does not
-        // own the row reads slot 0 and its result is dropped
+        // outermost: GT independent FMA chains are in flight, a tree that does not own the row reads
+        // slot 0 and its result is dropped.  The GT lane-sums are reduced together
+        // (wave_sum_multi): tree gi's dot arrives in lane gi * LSTEP, the lane that holds the
+        // row's (task, position) for that tree and writes its side byte.
         auto process = [&](const float4(&xr)[NV], int ma, int mp) {
-            int a[GT], p[GT];
             const float4 *hv[GT];
             Acc4 c[GT];
 #pragma unroll
             for (int gi = 0; gi < GT; gi++) {
-                a[gi] = __builtin_amdgcn_readlane(ma, gi);   // v_readlane: lanes >= ng hold -1
-                p[gi] = __builtin_amdgcn_readlane(mp, gi);
-                hv[gi] = hs + (a[gi] < 0 ? 0 : a[gi] - a0) * nvec + lane;
+                const int a = __builtin_amdgcn_readlane(ma, gi * LSTEP);   // lanes of absent trees hold -1
+                hv[gi] = hs + (a < 0 ? 0 : a - a0) * nvec + lane;
                 c[gi] = acc4_zero();
             }
 #pragma unroll
@@ -513,18 +539,15 @@ __global__ __launch_bounds__(RW_THREADS) void split_rw_kernel(
 #pragma unroll
                 for (int gi = 0; gi < GT; gi++) fma4(c[gi], xr[k], hv[gi][k * WAVE]);
             }
-            float d[GT];
+            float f[GT];
 #pragma unroll
-            for (int gi = 0; gi < GT; gi++) d[gi] = acc4_finish(c[gi]);
-#pragma unroll
-            for (int gi = 0; gi < GT; gi++) {
-                if (a[gi] < 0) continue;
-                const int s = a[gi] - a0;
-                const int sd = d[gi] != 0.f ? (d[gi] > 0.f) : pos_flip(s_seed[s], (uint32_t)p[gi]);
-                if (lane == 0) {
-                    side[(int64_t)(t0 + gi) * n_items + s_start[s] + p[gi]] = (uint8_t)sd;
-                    if (sd) atomicAdd(&s_ones[s], 1);
-                }
+            for (int gi = 0; gi < GT; gi++) f[gi] = (c[gi].lo.x + c[gi].lo.y) + (c[gi].hi.x + c[gi].hi.y);
+            const float d = wave_sum_multi<GT>(f, lane);
+            if (ma >= 0) {   // only lanes gi * LSTEP of present trees
+                const int s = ma - a0;
+                const int sd = d != 0.f ? (d > 0.f) : pos_flip(s_seed[s], (uint32_t)mp);
+                side[(int64_t)(t0 + lane / LSTEP) * n_items + s_start[s] + mp] = (uint8_t)sd;
+                if (sd) atomicAdd(&s_ones[s], 1);
             }
         };
         auto valid = [&](int rr) { return rr < RW_ROWS && row_base + rr < n_items; };
@@ -805,7 +828,8 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             const bool use_rw = attempt == 0 && max_per_tree >= 1 && max_per_tree <= std::min(rw_max, RW_SLOTS / 2) &&
                                 nv_ok && rows * 2 >= (int64_t)n_trees * N;
             if (use_rw) {
-                const int G = RW_SLOTS / (max_per_tree == 3 ? 4 : max_per_tree);
+                // trees per group: 8 / 4 / 3 / 2 with 1 / 2 / 3-4 / 5-6 split nodes per tree (<= RW_SLOTS hyperplanes)
+                const int G = max_per_tree == 1 ? 8 : max_per_tree == 2 ? 4 : max_per_tree <= 4 ? 3 : 2;
                 const int n_windows = (int)((N + RW_ROWS - 1) / RW_ROWS), n_groups = (n_trees + G - 1) / G;
                 if ((rc = row_task.alloc((size_t)n_trees * N)) || (rc = row_pos.alloc((size_t)n_trees * N)) ||
                     (rc = d_tree_first.alloc((size_t)n_trees + 1))) { cleanup(); return rc; }
@@ -815,7 +839,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                                    h->perm.p, N, row_task.p, row_pos.p);
                 ScopedTimer tm(h, MORNA_T_SPLIT, 4 * (int64_t)D * (rows + A));
                 const unsigned grid = 8u * (unsigned)((n_windows + 7) / 8) * (unsigned)n_groups;
-                const size_t lds = (size_t)RW_SLOTS * dpad * 4;
+                const size_t lds = (size_t)G * max_per_tree * dpad * 4;
 #define RW_LAUNCH_G(NVV, GTT)                                                                                            \
     do {                                                                                                                 \
         F_TRY(hipFuncSetAttribute((const void *)split_rw_kernel<NVV, GTT>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
@@ -828,6 +852,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
     do {                                        \
         if (G == 8) RW_LAUNCH_G(NVV, 8);        \
         else if (G == 4) RW_LAUNCH_G(NVV, 4);   \
+        else if (G == 3) RW_LAUNCH_G(NVV, 3);   \
         else RW_LAUNCH_G(NVV, 2);               \
     } while (0)
                 if (nv == 1) RW_LAUNCH(1);
