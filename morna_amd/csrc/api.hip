@@ -110,6 +110,10 @@ int morna_index_create(int32_t dim, int32_t device, morna_index **out)
     h->dpad = (dim + 255) / 256 * 256;   // whole 1-KiB wave loads: every lane active in every k-step
     h->K = dim + 2;
     h->device = device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->n_cus = cus;
+    }
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         set_error("hipStreamCreate: %s", hipGetErrorString(e));

@@ -98,6 +98,7 @@ struct morna_index {
     int32_t dim = 0;     // D (f in annoy)
     int32_t dpad = 0;    // row stride in floats: D rounded up to 256 (one 1-KiB load per wave and k-step)
     int32_t device = 0;
+    int32_t n_cus = 256;               // compute units of the device (MI355X: 256)
     int32_t K = 0;       // leaf capacity D + 2
     hipStream_t stream = nullptr;
 

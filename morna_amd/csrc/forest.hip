@@ -295,6 +295,151 @@ __global__ __launch_bounds__(256) void two_means_wave_kernel(const float *__rest
     for (int kk = 0; kk < NV; kk++) out[lane + kk * WAVE] = p[kk];
 }
 
+// ---- two_means, FOUR waves per node ---------------------------------------------------
+// The 200 steps of a node are one dependent chain, and most of a step is elementwise: the
+// IEEE divisions of the centroid update, (c * n + x / |x|) / (n + 1), 96 per lane.  Here
+// every wave of a 4-wave workgroup keeps p and q in registers and makes the same decision
+// from the same dots, but updates only ITS quarter of the chosen centroid and fetches only its
+// quarter of the coming rows; quarters are exchanged through LDS (one barrier per step, buffers
+// alternate).  The Kiss32 stream does not depend on data, so the row index is fetched three
+// steps ahead and the row two steps ahead: no step waits for the index -> row load chain.
+// Same operations on the same values as two_means_wave_kernel.
+
+// this wave's quarter of centroid c, picked with selects (w is wave-uniform): indexing the register
+// array with w, or passing it to a function per value of w, would move it to scratch memory
+template <int NV>
+__device__ inline float4 quad_pick(const float4 (&c)[NV], int w, int s)
+{
+    constexpr int NS = NV / 4;
+    const float4 a = c[s], b = c[NS + s], d = c[2 * NS + s], e = c[3 * NS + s];
+    float4 r;
+    EW4(r, w == 0 ? a.x : (w == 1 ? b.x : (w == 2 ? d.x : e.x)), w == 0 ? a.y : (w == 1 ? b.y : (w == 2 ? d.y : e.y)),
+        w == 0 ? a.z : (w == 1 ? b.z : (w == 2 ? d.z : e.z)), w == 0 ? a.w : (w == 1 ? b.w : (w == 2 ? d.w : e.w)));
+    return r;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void two_means_quad_kernel(const float *__restrict__ X, const float *__restrict__ norm2,
+                                                             int64_t n_items, int32_t dpad,
+                                                             const int32_t *__restrict__ perm,
+                                                             const SplitTask *__restrict__ tasks, uint32_t seed,
+                                                             float *__restrict__ hp)
+{
+    static_assert(NV % 4 == 0, "a wave owns NV / 4 float4 per lane");
+    constexpr int NS = NV / 4;
+    __shared__ float4 rbuf[2][NV * WAVE];   // the row of step l sits in rbuf[l & 1]
+    __shared__ float4 cbuf[2][NV * WAVE];   // the centroid updated in step l, cbuf[l & 1]
+
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    const SplitTask t = tasks[blockIdx.x];
+    const int nvec = dpad / 4;
+    const int32_t *items = perm + (int64_t)t.tree * n_items + t.start;
+    // every wave runs the node's Kiss32 stream itself: no index is exchanged
+    Kiss32 rng(node_seed(seed, (uint32_t)t.tree, (uint32_t)t.level, (uint32_t)t.start, (uint32_t)t.attempt));
+
+    uint32_t i = rng.index((uint32_t)t.count);
+    uint32_t j = rng.index((uint32_t)t.count - 1u);
+    j += (j >= i);
+    float4 p[NV], q[NV];
+    reg_load_row<NV>(X + (int64_t)items[i] * dpad, nvec, lane, p);
+    reg_load_row<NV>(X + (int64_t)items[j] * dpad, nvec, lane, q);
+    reg_normalize<NV>(p);
+    reg_normalize<NV>(q);
+    float pp = reg_dot<NV>(p, p), qq = reg_dot<NV>(q, q);
+
+    // rows of steps 0, 1, 2 (draws beyond step 199 are never used: the stream is the node's own)
+    const int32_t it0 = items[rng.index((uint32_t)t.count)];
+    int32_t it1 = items[rng.index((uint32_t)t.count)];
+    int32_t it2 = items[rng.index((uint32_t)t.count)];
+    const int soff = (w * NS) * WAVE + lane;   // this wave's quarter of a row
+    float4 xs1[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) xs1[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        const float4 *x0 = (const float4 *)(X + (int64_t)it0 * dpad) + soff;
+        const float4 *x1 = (const float4 *)(X + (int64_t)it1 * dpad) + soff;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            rbuf[0][soff + s * WAVE] = x0[s * WAVE];
+            xs1[s] = x1[s * WAVE];
+        }
+    }
+    float nk2 = norm2[it0], nk2_1 = norm2[it1];
+    __syncthreads();
+
+    int ic = 1, jc = 1;
+    for (int l = 0; l < TM_ITERS; l++) {
+        const int par = l & 1;
+        const float4 *xrow = rbuf[par];
+        // row l+1 (requested a step ago) goes to the other buffer -- nobody reads it after the last
+        // barrier -- and the same registers then receive this wave's quarter of row l+2; the index of
+        // row l+3 and the norm of row l+2 are requested as well
+#pragma unroll
+        for (int s = 0; s < NS; s++) rbuf[par ^ 1][soff + s * WAVE] = xs1[s];
+        const int32_t it3 = items[rng.index((uint32_t)t.count)];
+        {
+            const float4 *x2 = (const float4 *)(X + (int64_t)it2 * dpad) + soff;
+#pragma unroll
+            for (int s = 0; s < NS; s++) xs1[s] = x2[s * WAVE];
+        }
+        const float nk2_2 = norm2[it2];
+        // both dots against the row in LDS, reduced together (p.x in lane 0, q.x in lane 32)
+        Acc4 a = acc4_zero(), b = acc4_zero();
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            const float4 xv = xrow[k * WAVE + lane];
+            fma4(a, p[k], xv);
+            fma4(b, q[k], xv);
+        }
+        const float f[2] = {(a.lo.x + a.lo.y) + (a.hi.x + a.hi.y), (b.lo.x + b.lo.y) + (b.hi.x + b.hi.y)};
+        const float u = wave_sum_multi<2>(f, lane);
+        const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u), 0));
+        const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u), 32));
+        const float di = (float)ic * ang_dist(pp, nk2, px);
+        const float dj = (float)jc * ang_dist(qq, nk2, qx);
+        const float norm = sqrtf(nk2);
+        int upd = 0;   // the same in all four waves
+        if (norm > 0.f) upd = di < dj ? 1 : (dj < di ? 2 : 0);
+        if (upd) {
+            const float f0 = upd == 1 ? (float)ic : (float)jc, f1 = f0 + 1.f;   // counts are small integers: exact
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const float4 c1 = quad_pick<NV>(p, w, s), c2 = quad_pick<NV>(q, w, s);
+                float4 c, v;
+                EW4(c, upd == 1 ? c1.x : c2.x, upd == 1 ? c1.y : c2.y, upd == 1 ? c1.z : c2.z, upd == 1 ? c1.w : c2.w);
+                const float4 xv = xrow[soff + s * WAVE];
+                EW4(v, (c.x * f0 + xv.x / norm) / f1, (c.y * f0 + xv.y / norm) / f1, (c.z * f0 + xv.z / norm) / f1,
+                    (c.w * f0 + xv.w / norm) / f1);
+                cbuf[par][soff + s * WAVE] = v;
+            }
+        }
+        __syncthreads();
+        if (upd == 1) {
+#pragma unroll
+            for (int kk = 0; kk < NV; kk++) p[kk] = cbuf[par][kk * WAVE + lane];
+            pp = reg_dot<NV>(p, p);
+            ic++;
+        } else if (upd == 2) {
+#pragma unroll
+            for (int kk = 0; kk < NV; kk++) q[kk] = cbuf[par][kk * WAVE + lane];
+            qq = reg_dot<NV>(q, q);
+            jc++;
+        }
+        it2 = it3;
+        nk2 = nk2_1;
+        nk2_1 = nk2_2;
+    }
+    (void)it1;
+    if (w != 0) return;
+    // create_split: n = normalize(p - q)
+#pragma unroll
+    for (int kk = 0; kk < NV; kk++) EW4(p[kk], p[kk].x - q[kk].x, p[kk].y - q[kk].y, p[kk].z - q[kk].z, p[kk].w - q[kk].w);
+    reg_normalize<NV>(p);
+    float4 *out = (float4 *)(hp + (int64_t)t.slot * dpad);
+#pragma unroll
+    for (int kk = 0; kk < NV; kk++) out[lane + kk * WAVE] = p[kk];
+}
+
 // ---------------------------------------------------------------- split kernel
 
 #define SP_THREADS 256
@@ -788,7 +933,20 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
 #define TMW_LAUNCH(NVV)                                                                                              \
     hipLaunchKernelGGL(two_means_wave_kernel<NVV>, dim3(wg), dim3(256), 0, h->stream, h->X.p, h->norm2.p, N, dpad, \
                        h->perm.p, d_tasks.p, A, seed, hp_level)
-                if (nvq == 1) TMW_LAUNCH(1);
+                // Four waves per node while the level's nodes fit the chip at once (2 workgroups per CU): the
+                // node's 200-step chain is then ~1.6x shorter (C3: 0.45 / 0.62 ms instead of 0.73 / 0.75 ms at
+                // the two shallowest levels).  Deeper levels are bound by VALU throughput, not by the chain, and
+                // four waves only add redundant work there (C3, 1600 nodes: 2.0 ms instead of 1.2 ms).
+                // MORNA_TM_QUAD=0: one wave per node everywhere.
+                static const bool tm_quad_on = !(getenv("MORNA_TM_QUAD") && atoi(getenv("MORNA_TM_QUAD")) == 0);
+                const bool tm_quad = tm_quad_on && A <= 2 * h->n_cus;
+#define TMQ_LAUNCH(NVV)                                                                                                  \
+    hipLaunchKernelGGL(two_means_quad_kernel<NVV>, dim3((unsigned)A), dim3(256), 0, h->stream, h->X.p, h->norm2.p, N, dpad, \
+                       h->perm.p, d_tasks.p, seed, hp_level)
+                if (tm_quad && nvq == 12) TMQ_LAUNCH(12);
+                else if (tm_quad && nvq == 8) TMQ_LAUNCH(8);
+                else if (tm_quad && nvq == 4) TMQ_LAUNCH(4);
+                else if (nvq == 1) TMW_LAUNCH(1);
                 else if (nvq == 2) TMW_LAUNCH(2);
                 else if (nvq == 3) TMW_LAUNCH(3);
                 else if (nvq == 4) TMW_LAUNCH(4);
@@ -799,6 +957,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                     hipLaunchKernelGGL(two_means_kernel, dim3((unsigned)A), dim3(TM_THREADS), (size_t)dpad * 4 * 3, h->stream,
                                        h->X.p, h->norm2.p, N, dpad, h->perm.p, d_tasks.p, seed, hp_level);
 #undef TMW_LAUNCH
+#undef TMQ_LAUNCH
             }
             {
                 // launch order: chunks sorted by first row id, one contiguous run per XCD

@@ -243,6 +243,7 @@ def _compare_forest(a, o, N, T):
 
 
 @pytest.mark.parametrize("f,N,T", [(16, 3000, 8), (40, 5000, 5), (300, 4000, 3),
+                                   (1000, 3000, 3), (2000, 4500, 2),   # 4 and 8 float4 per lane: four-wave two_means
                                    (3000, 8000, 11),    # the bench's row width: register two_means + row-window split,
                                                         # 11 trees = one full and one partial tree group
                                    (8192, 9000, 2)])    # config 5's width: LDS two_means + chunk split
