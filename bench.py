@@ -57,6 +57,52 @@ def parse():
     return ap.parse_args()
 
 
+def _cpu_baseline_mt(args, capi, X, items, N, D, t_feat, t_dot):
+    """The same port on the box's host cores (SURVEY.md 8d "cpu-ref-mt"): trees are independent, so every
+    thread builds one tree with its own oracle instance (the C calls release the GIL), then answers a share
+    of the queries against it.  The feature pass stays sequential (file order is part of its definition)."""
+    import threading
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 16))
+    if threads < 2:
+        return None
+    orc = [capi.AnnoyOracle(D, mode=0, seed=1000 + i) for i in range(threads)]
+    for o in orc:
+        o.set_items(X)
+    nq = max(1, min(args.cpu_queries, len(items)) // threads)
+    t_build = [0.0] * threads
+    t_query = [0.0] * threads
+
+    def work(i):
+        t0 = time.perf_counter()
+        orc[i].build(1)
+        t_build[i] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for it in items[i * nq:(i + 1) * nq]:
+            orc[i].get_nns_by_item(int(it), args.k, args.search_k)
+        t_query[i] = time.perf_counter() - t0
+    th = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    # threads trees were built in max(t_build) seconds; a query costs its single-tree time plus the root dots
+    # of the other trees, and threads of them run at once
+    forest = max(t_build) * args.trees / threads
+    t_q = max(t_query) / nq + (args.trees - 1) * t_dot
+    queries = t_q * args.queries / threads
+    total = t_feat + forest + queries
+    return dict(value=N / total, unit="samples/s", cores=threads, kind="port",
+                sample=("oracle/ on %d threads, one oracle instance and one tree per thread (%.1fs wall), %d queries per "
+                        "thread; extrapolated: features %.1fs (sequential) + forest %.1fs + queries %.1fs"
+                        % (threads, wall, nq, t_feat, forest, queries)))
+
+
 def cpu_baseline(args, data, prep, items):
     """Oracle (port of morna.py + annoy, 1 thread) on a bounded sample, extrapolated."""
     from oracle import capi
@@ -85,15 +131,20 @@ def cpu_baseline(args, data, prep, items):
     for it in items[:nq]:
         o.get_nns_by_item(int(it), args.k, args.search_k)
     t_q_small = (time.perf_counter() - t0) / nq
-    # price the missing root dots: (trees - cpu_trees) extra dots of length D per query
-    xs = X[:64]
+    # price the root dots of the trees that were not built: the same queries against a 1-tree forest give the
+    # cost of one more tree per query (all measured inside the C oracle)
+    o1 = capi.AnnoyOracle(D, mode=0, seed=77)
+    o1.set_items(X)
+    o1.build(1)
     t0 = time.perf_counter()
-    for _ in range(4):
-        for r in xs:
-            capi.dot(0, r, xs[0])
-    t_dot = (time.perf_counter() - t0) / (4 * len(xs))
+    for it in items[:nq]:
+        o1.get_nns_by_item(int(it), args.k, args.search_k)
+    t_q_one = (time.perf_counter() - t0) / nq
+    del o1
+    t_dot = max(t_q_small - t_q_one, 0.0) / max(args.cpu_trees - 1, 1)
     t_q = t_q_small + (args.trees - args.cpu_trees) * t_dot
     total = t_feat + t_tree * args.trees + t_q * args.queries
+    cpu_baseline.mt = _cpu_baseline_mt(args, capi, X, items, N, D, t_feat, t_dot)
     return dict(value=N / total, unit="samples/s", cores=1, kind="port",
                 sample=("oracle/ (C restatement of morna.py add_junction + annoy, 1 thread): features on the first "
                         "%d of %d junction lines, %d of %d trees on the full %dx%d matrix, %d of %d queries; "
@@ -256,6 +307,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             prep["X_host"] = index.get_items()
             out["cpu_baseline"] = cpu_baseline(args, data, prep, items)
+            out["cpu_baseline_mt"] = getattr(cpu_baseline, "mt", None)   # extra: the port on all host cores
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
