@@ -75,6 +75,15 @@ struct ScratchRef {
     }
 };
 
+// one split attempt of one node, as the forest kernels see it
+struct SplitTask {
+    int32_t tree, level, start, count;
+    int32_t slot;      // hyperplane slot
+    int32_t attempt;
+    int32_t chunk0;    // first chunk index of this task in the split kernel grid
+    int32_t pad;
+};
+
 // A node of the forest as the host driver tracks it (perm segment of one tree).
 struct Seg {
     int32_t tree, level, start, count, node;
@@ -183,6 +192,10 @@ int build_features(morna_index *h, int64_t n_items);
 int hash_keys_device(morna_index *h, const uint8_t *key_bytes, const int64_t *key_off, int64_t J,
                      int32_t *hash_out, int32_t *col_out, int32_t *sign_out);
 int build_forest(morna_index *h, int32_t n_trees, uint32_t seed);
+// splitmm.hip: the split of a whole level on the matrix cores (fp16 filter, exact fp32 for what it cannot decide)
+int split_mm_prepare_rows(morna_index *h);
+int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, const float *hp_level,
+                   const int32_t *row_task, const int32_t *row_pos, uint32_t seed, uint8_t *side, int32_t *ones);
 int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int32_t *items_host, int64_t nq, int32_t k,
                 int32_t search_k, int32_t *ids_out, float *dist_out, int32_t *count_out);
 int exact_search(morna_index *h, const double *q, int64_t nq, int32_t k, int32_t *ids_out,

@@ -34,15 +34,6 @@
 
 namespace morna {
 
-// one split attempt of one node, as the kernels see it
-struct SplitTask {
-    int32_t tree, level, start, count;
-    int32_t slot;      // hyperplane slot
-    int32_t attempt;
-    int32_t chunk0;    // first chunk index of this task in the split kernel grid
-    int32_t pad;
-};
-
 #define TM_THREADS 256
 #define TM_ITERS 200
 
@@ -866,6 +857,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
     std::vector<SplitTask> tasks;
     std::vector<int32_t> h_ones;
     int32_t level = 0;
+    bool half_rows_ready = false;   // fp16 image of the rows (splitmm.hip), made once per build
 
     auto cleanup = [&]() {};
 #define F_TRY(e)                                                    \
@@ -986,16 +978,35 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             const bool nv_ok = nv == 1 || nv == 2 || nv == 3 || nv == 4 || nv == 6 || nv == 8 || nv == 12;
             const bool use_rw = attempt == 0 && max_per_tree >= 1 && max_per_tree <= std::min(rw_max, RW_SLOTS / 2) &&
                                 nv_ok && rows * 2 >= (int64_t)n_trees * N;
-            if (use_rw) {
-                // trees per group: 8 / 4 / 3 / 2 with 1 / 2 / 3-4 / 5-6 split nodes per tree (<= RW_SLOTS hyperplanes)
-                const int G = max_per_tree == 1 ? 8 : max_per_tree == 2 ? 4 : max_per_tree <= 4 ? 3 : 2;
-                const int n_windows = (int)((N + RW_ROWS - 1) / RW_ROWS), n_groups = (n_trees + G - 1) / G;
+            // While a tree has few split nodes and most rows still sit in split nodes, the whole level is one
+            // contraction on the matrix cores (splitmm.hip): its cost grows with the nodes per tree (every row
+            // meets every hyperplane), the chunk form's does not -- they meet near 64 nodes per tree.
+            // MORNA_SPLIT_MM=0 turns it off (row-window / chunk forms as before).
+            static const bool mm_on = !(getenv("MORNA_SPLIT_MM") && atoi(getenv("MORNA_SPLIT_MM")) == 0);
+            const bool use_mm = mm_on && attempt == 0 && max_per_tree >= 1 && max_per_tree <= 32 &&
+                                rows * 2 >= (int64_t)n_trees * N;
+            if (use_mm || use_rw) {   // row -> (task, position) per tree
                 if ((rc = row_task.alloc((size_t)n_trees * N)) || (rc = row_pos.alloc((size_t)n_trees * N)) ||
                     (rc = d_tree_first.alloc((size_t)n_trees + 1))) { cleanup(); return rc; }
                 F_TRY(hipMemcpyAsync(d_tree_first.p, tree_first.data(), ((size_t)n_trees + 1) * 4, hipMemcpyHostToDevice, h->stream));
                 F_TRY(hipMemsetAsync(row_task.p, 0xFF, (size_t)n_trees * N * 4, h->stream));
                 hipLaunchKernelGGL(invert_kernel, dim3((unsigned)n_chunks), dim3(64), 0, h->stream, d_tasks.p, d_info.p, n_chunks,
                                    h->perm.p, N, row_task.p, row_pos.p);
+            }
+            if (use_mm) {
+                ScopedTimer tm(h, MORNA_T_SPLIT, 4 * (int64_t)D * (rows + A));
+                if (!half_rows_ready) {
+                    if ((rc = split_mm_prepare_rows(h))) { cleanup(); return rc; }
+                    half_rows_ready = true;
+                }
+                if ((rc = split_mm_level(h, d_tasks.p, A, hp_level, row_task.p, row_pos.p, seed, side.p, d_ones.p))) {
+                    cleanup();
+                    return rc;
+                }
+            } else if (use_rw) {
+                // trees per group: 8 / 4 / 3 / 2 with 1 / 2 / 3-4 / 5-6 split nodes per tree (<= RW_SLOTS hyperplanes)
+                const int G = max_per_tree == 1 ? 8 : max_per_tree == 2 ? 4 : max_per_tree <= 4 ? 3 : 2;
+                const int n_windows = (int)((N + RW_ROWS - 1) / RW_ROWS), n_groups = (n_trees + G - 1) / G;
                 ScopedTimer tm(h, MORNA_T_SPLIT, 4 * (int64_t)D * (rows + A));
                 const unsigned grid = 8u * (unsigned)((n_windows + 7) / 8) * (unsigned)n_groups;
                 const size_t lds = (size_t)G * max_per_tree * dpad * 4;

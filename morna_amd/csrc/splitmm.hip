@@ -1,0 +1,253 @@
+// splitmm.hip -- the split of a whole forest level as ONE contraction on the matrix cores.
+//
+// Counterpart of the inner loop of annoy's _make_tree (called from AnnoyIndex.build,
+// commanderson/morna morna.py:425): every row of a split node gets side = sign(dot(row, hyperplane)).
+// Over a level that is C[row][node] = sum_d X[row][d] H[node][d] for all rows and all split nodes of
+// all trees; the entry a row needs is the one of ITS node in each tree.  While a tree has few split
+// nodes, computing the whole product on v_mfma_f32_32x32x16_f16 is far cheaper than streaming each
+// row once per tree through the vector ALUs (C3, fourth level: 2.5e11 MAC against 120 GB of L2 -> CU
+// traffic).
+//
+// The product is taken on fp16 COPIES of the rows and hyperplanes (each scaled by a power of two so
+// that its largest element lies in [2^14, 2^15)), and it only FILTERS: with y = fp16(s x), g = fp16(t h),
+//   |sum y_i g_i (as computed) - s t dot(x, h)|  <=  EPS * |y| * |g|,
+//   EPS = 2^-10 (two roundings to 11 bits) + 4 * dpad * 2^-24 (fp32 accumulation of dpad products in any
+//         order, with room for adders that truncate) + the rounding of the canonical fp32 dot itself (< 4e-6),
+// so whenever |C| > EPS |y| |g| the sign of C IS the sign of the canonical wave_dot the split is defined
+// by.  The (row, node) pairs the filter cannot decide -- about 1 % -- are listed and recomputed by
+// split_amb_kernel with wave_dot on the fp32 data, including the dot == 0 coin flip.  The sides written
+// are therefore exactly those of split_kernel; the forest stays bit-identical to the oracle.
+#include "common.hpp"
+#include "devutil.hpp"
+
+namespace morna {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline float sm_eps(int32_t dpad) { return 1.02f * 0.0009765625f + 4.f * (float)dpad * 5.9604645e-8f + 4e-6f; }
+
+// ---- fp16 image of a row-major fp32 matrix: one wave per row ---------------------------------------
+// dst row = fp16(2^e * src row) with max |2^e x_i| in [2^14, 2^15); norm[row] = an upper bound of the
+// Euclidean norm of the fp16 row (+inf when the row cannot be scaled into range: it is then never
+// decided by the filter).
+__global__ __launch_bounds__(256) void rows_to_half_kernel(const float *__restrict__ src, int64_t rows, int32_t dpad,
+                                                           _Float16 *__restrict__ dst, float *__restrict__ norm)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t r = (int64_t)blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
+    if (r >= rows) return;
+    const float4 *x = (const float4 *)(src + r * dpad);
+    const int nvec = dpad / 4;
+    float m = 0.f;
+    bool bad = false;
+    for (int i = lane; i < nvec; i += WAVE) {
+        const float4 v = x[i];
+        const float a = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        bad |= !(a <= 3.0e38f);   // inf or NaN
+        m = fmaxf(m, a);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, WAVE));
+    bad = __any(bad);
+    int e = 0;
+    if (m > 0.f) e = 14 - ilogbf(m);
+    if (e > 126 || e < -126) bad = true;   // the scale itself must be a normal float
+    const float s = bad ? 0.f : ldexpf(1.f, e);
+    float sum = 0.f;
+    _Float16 *d = dst + r * dpad;
+    for (int i = lane; i < nvec; i += WAVE) {
+        const float4 v = x[i];
+        const _Float16 h0 = (_Float16)(v.x * s), h1 = (_Float16)(v.y * s), h2 = (_Float16)(v.z * s), h3 = (_Float16)(v.w * s);
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        *(f16x4 *)(d + 4 * i) = (f16x4){h0, h1, h2, h3};
+        const float f0 = (float)h0, f1 = (float)h1, f2 = (float)h2, f3 = (float)h3;
+        sum += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+    }
+    sum = wave_sum_xor(sum);
+    // fp32 sum of <= 8192 squares: relative error < 1e-3; the bound is widened by that much
+    if (lane == 0) norm[r] = bad ? INFINITY : sqrtf(sum) * 1.002f;
+}
+
+// ---- the contraction with the side decision fused into its epilogue --------------------------------
+#define SM_TILE 128
+#define SM_BK 64                 // halfs per K step
+#define SM_LD (SM_BK + 8)        // 144-byte LDS rows: 16-byte accesses stay aligned, rows fall on different banks
+
+__global__ __launch_bounds__(256) void split_mm_kernel(
+    const _Float16 *__restrict__ X16, const float *__restrict__ xn, int64_t n_items, int32_t dpad,
+    const _Float16 *__restrict__ H16, const float *__restrict__ hn, int32_t n_tasks,
+    const SplitTask *__restrict__ tasks, const int32_t *__restrict__ row_task, const int32_t *__restrict__ row_pos,
+    float eps, uint8_t *__restrict__ side, int32_t *__restrict__ ones, unsigned int *__restrict__ amb_count,
+    int2 *__restrict__ amb, unsigned int amb_cap)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 As[SM_TILE * SM_LD];   // rows        [128][72]
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[SM_TILE * SM_LD];   // hyperplanes [128][72]
+    __shared__ int s_ones[SM_TILE];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int wm = w >> 1, wn = w & 1;   // the wave's 64 x 64 quadrant
+    const int64_t r0 = (int64_t)blockIdx.x * SM_TILE;
+    const int c0 = (int)blockIdx.y * SM_TILE;
+
+    uint4 ga[4], gb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int idx = tid + it * 256, row = idx >> 3, c8 = idx & 7;   // 8 x 16 bytes = 64 halfs per row
+            ga[it] = r0 + row < n_items ? *(const uint4 *)(X16 + (r0 + row) * dpad + k0 + c8 * 8) : make_uint4(0, 0, 0, 0);
+            gb[it] = c0 + row < n_tasks ? *(const uint4 *)(H16 + (int64_t)(c0 + row) * dpad + k0 + c8 * 8)
+                                        : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int idx = tid + it * 256, row = idx >> 3, c8 = idx & 7;
+            *(uint4 *)(As + row * SM_LD + c8 * 8) = ga[it];
+            *(uint4 *)(Bs + row * SM_LD + c8 * 8) = gb[it];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+    if (tid < SM_TILE) s_ones[tid] = 0;
+
+    fetch(0);
+    stash();
+    __syncthreads();
+    const int lr = lane & 31, lh = lane >> 5;
+    for (int k0 = 0; k0 < dpad; k0 += SM_BK) {
+        const bool more = k0 + SM_BK < dpad;
+        if (more) fetch(k0 + SM_BK);   // next K slab in flight under the MFMAs
+#pragma unroll
+        for (int blk = 0; blk < SM_BK / 16; blk++) {
+            // 32x32x16: lane (r = l & 31, h = l >> 5) supplies A[row r][k = 8h + j], B[k = 8h + j][col r], j = 0..7
+            f16x8 a8[2], b8[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                a8[t] = *(const f16x8 *)(As + (wm * 64 + t * 32 + lr) * SM_LD + blk * 16 + lh * 8);
+                b8[t] = *(const f16x8 *)(Bs + (wn * 64 + t * 32 + lr) * SM_LD + blk * 16 + lh * 8);
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                for (int tn = 0; tn < 2; tn++)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8[tm], b8[tn], acc[tm][tn], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) stash();
+        __syncthreads();
+    }
+
+    // epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31 (a hyperplane = a task), row = (e & 3) +
+    // 8 * (e >> 2) + 4 * (lane >> 5).  An entry matters only when the row sits in that task's node.
+#pragma unroll
+    for (int tn = 0; tn < 2; tn++) {
+        const int cl = wn * 64 + tn * 32 + lr, col = c0 + cl;
+        if (col >= n_tasks) continue;
+        const SplitTask t = tasks[col];
+        const float bound = eps * hn[col];
+        const int32_t *rt = row_task + (int64_t)t.tree * n_items;
+        const int32_t *rp = row_pos + (int64_t)t.tree * n_items;
+        uint8_t *sd = side + (int64_t)t.tree * n_items + t.start;
+        int my_ones = 0;
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int64_t row = r0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (row >= n_items || rt[row] != col) continue;
+                const float c = acc[tm][tn][e];
+                if (fabsf(c) > bound * xn[row]) {   // false for NaN and for rows / hyperplanes that could not be scaled
+                    const int s = c > 0.f;
+                    sd[rp[row]] = (uint8_t)s;
+                    my_ones += s;
+                } else {
+                    const unsigned int idx = atomicAdd(amb_count, 1u);
+                    if (idx < amb_cap) amb[idx] = make_int2((int)row, col);
+                }
+            }
+        }
+        if (my_ones) atomicAdd(&s_ones[cl], my_ones);
+    }
+    __syncthreads();
+    if (tid < SM_TILE && c0 + tid < n_tasks && s_ones[tid]) atomicAdd(&ones[c0 + tid], s_ones[tid]);
+}
+
+// ---- the pairs the filter left open: canonical fp32 dot, one wave per pair ------------------------
+__global__ __launch_bounds__(256) void split_amb_kernel(const float *__restrict__ X, int64_t n_items, int32_t dpad,
+                                                        const SplitTask *__restrict__ tasks,
+                                                        const int32_t *__restrict__ row_pos, uint32_t seed,
+                                                        const float *__restrict__ hp,
+                                                        const unsigned int *__restrict__ amb_count,
+                                                        const int2 *__restrict__ amb, unsigned int amb_cap,
+                                                        uint8_t *__restrict__ side, int32_t *__restrict__ ones)
+{
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    const int nvec = dpad / 4;
+    unsigned int n = *amb_count;
+    if (n > amb_cap) n = amb_cap;   // cannot happen: the list holds one entry per (row, tree) at most
+    for (unsigned int i = blockIdx.x * (256 / WAVE) + w; i < n; i += gridDim.x * (256 / WAVE)) {
+        const int2 pr = amb[i];
+        const SplitTask t = tasks[pr.y];
+        const float d = wave_dot((const float4 *)(X + (int64_t)pr.x * dpad), (const float4 *)(hp + (int64_t)t.slot * dpad),
+                                 nvec, lane);
+        if (lane == 0) {
+            const int pos = row_pos[(int64_t)t.tree * n_items + pr.x];
+            const uint32_t nseed = node_seed(seed, (uint32_t)t.tree, (uint32_t)t.level, (uint32_t)t.start, (uint32_t)t.attempt);
+            // Angular::side: dot != 0 ? dot > 0 : coin flip
+            const int s = d != 0.f ? (d > 0.f) : pos_flip(nseed, (uint32_t)pos);
+            side[(int64_t)t.tree * n_items + t.start + pos] = (uint8_t)s;
+            if (s) atomicAdd(&ones[pr.y], 1);
+        }
+    }
+}
+
+// scratch slots 19..23 of the handle: fp16 rows, their norms, fp16 hyperplanes of the level, their norms,
+// the open-pair list (first 16 bytes: its counter)
+int split_mm_prepare_rows(morna_index *h)
+{
+    ScratchRef<_Float16> x16(h->scratch[19]);
+    ScratchRef<float> xn(h->scratch[20]);
+    MORNA_TRY(x16.alloc((size_t)h->n_items * h->dpad));
+    MORNA_TRY(xn.alloc((size_t)h->n_items));
+    hipLaunchKernelGGL(rows_to_half_kernel, dim3((unsigned)((h->n_items + 3) / 4)), dim3(256), 0, h->stream, h->X.p,
+                       h->n_items, h->dpad, x16.p, xn.p);
+    HIP_TRY(hipGetLastError());
+    return MORNA_OK;
+}
+
+int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, const float *hp_level,
+                   const int32_t *row_task, const int32_t *row_pos, uint32_t seed, uint8_t *side, int32_t *ones)
+{
+    const int64_t N = h->n_items;
+    ScratchRef<_Float16> x16(h->scratch[19]), h16(h->scratch[21]);
+    ScratchRef<float> xn(h->scratch[20]), hn(h->scratch[22]);
+    ScratchRef<uint8_t> ambuf(h->scratch[23]);
+    const size_t cap = (size_t)N * h->n_trees;   // a row is in at most one split node per tree
+    if (cap > 0xFFFFFFF0u) {
+        set_error("split_mm_level: %lld x %d (row, tree) pairs exceed the open-pair list", (long long)N, h->n_trees);
+        return MORNA_E_INVALID;
+    }
+    MORNA_TRY(h16.alloc((size_t)n_tasks * h->dpad));
+    MORNA_TRY(hn.alloc((size_t)n_tasks));
+    MORNA_TRY(ambuf.alloc(16 + cap * sizeof(int2)));
+    unsigned int *amb_count = (unsigned int *)ambuf.p;
+    int2 *amb = (int2 *)(ambuf.p + 16);
+    HIP_TRY(hipMemsetAsync(amb_count, 0, 16, h->stream));
+    hipLaunchKernelGGL(rows_to_half_kernel, dim3((unsigned)((n_tasks + 3) / 4)), dim3(256), 0, h->stream, hp_level,
+                       (int64_t)n_tasks, h->dpad, h16.p, hn.p);
+    const dim3 grid((unsigned)((N + SM_TILE - 1) / SM_TILE), (unsigned)((n_tasks + SM_TILE - 1) / SM_TILE));
+    hipLaunchKernelGGL(split_mm_kernel, grid, dim3(256), 0, h->stream, x16.p, xn.p, N, h->dpad, h16.p, hn.p, n_tasks, d_tasks,
+                       row_task, row_pos, sm_eps(h->dpad), side, ones, amb_count, amb, (unsigned int)cap);
+    hipLaunchKernelGGL(split_amb_kernel, dim3((unsigned)(4 * h->n_cus)), dim3(256), 0, h->stream, h->X.p, N, h->dpad, d_tasks,
+                       row_pos, seed, hp_level, amb_count, amb, (unsigned int)cap, side, ones);
+    HIP_TRY(hipGetLastError());
+    return MORNA_OK;
+}
+
+}  // namespace morna
