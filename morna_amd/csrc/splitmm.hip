@@ -71,29 +71,38 @@ __global__ __launch_bounds__(256) void rows_to_half_kernel(const float *__restri
 
 // ---- the contraction with the side decision fused into its epilogue --------------------------------
 #define SM_TILE 128
+#define SM_THREADS 512           // 8 waves, each a 32 x 64 part of the tile: four workgroups per CU cover each other's loads
 #define SM_BK 64                 // halfs per K step
 #define SM_LD (SM_BK + 8)        // 144-byte LDS rows: 16-byte accesses stay aligned, rows fall on different banks
+#define SM_OPEN 1536             // open pairs a tile keeps in LDS (12 KB; ~500 expected of 16384 at the root level)
 
-__global__ __launch_bounds__(256) void split_mm_kernel(
+__global__ __launch_bounds__(SM_THREADS) void split_mm_kernel(
     const _Float16 *__restrict__ X16, const float *__restrict__ xn, int64_t n_items, int32_t dpad,
     const _Float16 *__restrict__ H16, const float *__restrict__ hn, int32_t n_tasks,
     const SplitTask *__restrict__ tasks, const int32_t *__restrict__ row_task, const int32_t *__restrict__ row_pos,
     float eps, uint8_t *__restrict__ side, int32_t *__restrict__ ones, unsigned int *__restrict__ amb_count,
     int2 *__restrict__ amb, unsigned int amb_cap)
 {
-    __shared__ __attribute__((aligned(16))) _Float16 As[SM_TILE * SM_LD];   // rows        [128][72]
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[SM_TILE * SM_LD];   // hyperplanes [128][72]
-    __shared__ int s_ones[SM_TILE];
+    // 64 KB: during the contraction the two operand slabs, afterwards the 128 x 128 result
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16 *As = (_Float16 *)smem;              // rows        [128][72]
+    _Float16 *Bs = As + SM_TILE * SM_LD;          // hyperplanes [128][72]
+    float *Cs = (float *)smem;                    // result      [128 hyperplanes][128 rows]
+    __shared__ int s_ones[SM_TILE], s_tree[SM_TILE], s_start[SM_TILE];
+    __shared__ float s_hn[SM_TILE];
+    __shared__ int2 s_open[SM_OPEN];   // pairs this tile's filter left open
+    __shared__ int s_nopen;
+    __shared__ unsigned int s_obase;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
-    const int wm = w >> 1, wn = w & 1;   // the wave's 64 x 64 quadrant
+    const int wm = w >> 1, wn = w & 1;   // the wave's part of the tile: rows wm * 32 .. +31, columns wn * 64 .. +63
     const int64_t r0 = (int64_t)blockIdx.x * SM_TILE;
     const int c0 = (int)blockIdx.y * SM_TILE;
 
-    uint4 ga[4], gb[4];
+    uint4 ga[2], gb[2];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int it = 0; it < 4; it++) {
-            const int idx = tid + it * 256, row = idx >> 3, c8 = idx & 7;   // 8 x 16 bytes = 64 halfs per row
+        for (int it = 0; it < 2; it++) {
+            const int idx = tid + it * SM_THREADS, row = idx >> 3, c8 = idx & 7;   // 8 x 16 bytes = 64 halfs per row
             ga[it] = r0 + row < n_items ? *(const uint4 *)(X16 + (r0 + row) * dpad + k0 + c8 * 8) : make_uint4(0, 0, 0, 0);
             gb[it] = c0 + row < n_tasks ? *(const uint4 *)(H16 + (int64_t)(c0 + row) * dpad + k0 + c8 * 8)
                                         : make_uint4(0, 0, 0, 0);
@@ -101,20 +110,26 @@ __global__ __launch_bounds__(256) void split_mm_kernel(
     };
     auto stash = [&]() {
 #pragma unroll
-        for (int it = 0; it < 4; it++) {
-            const int idx = tid + it * 256, row = idx >> 3, c8 = idx & 7;
+        for (int it = 0; it < 2; it++) {
+            const int idx = tid + it * SM_THREADS, row = idx >> 3, c8 = idx & 7;
             *(uint4 *)(As + row * SM_LD + c8 * 8) = ga[it];
             *(uint4 *)(Bs + row * SM_LD + c8 * 8) = gb[it];
         }
     };
-    f32x16 acc[2][2];
+    f32x16 acc[2];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 2; j++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-    if (tid < SM_TILE) s_ones[tid] = 0;
+        for (int e = 0; e < 16; e++) acc[j][e] = 0.f;
+    if (tid < SM_TILE) {
+        const int col = c0 + tid < n_tasks ? c0 + tid : n_tasks - 1;
+        const SplitTask t = tasks[col];
+        s_ones[tid] = 0;
+        if (tid == 0) s_nopen = 0;
+        s_tree[tid] = t.tree;
+        s_start[tid] = t.start;
+        s_hn[tid] = hn[col];
+    }
 
     fetch(0);
     stash();
@@ -125,54 +140,99 @@ __global__ __launch_bounds__(256) void split_mm_kernel(
         if (more) fetch(k0 + SM_BK);   // next K slab in flight under the MFMAs
 #pragma unroll
         for (int blk = 0; blk < SM_BK / 16; blk++) {
-            // 32x32x16: lane (r = l & 31, h = l >> 5) supplies A[row r][k = 8h + j], B[k = 8h + j][col r], j = 0..7
-            f16x8 a8[2], b8[2];
+            // 32x32x16: lane (r = l & 31, h = l >> 5) supplies A[m = r][k = 8h + j], B[k = 8h + j][n = r], j = 0..7.
+            // The HYPERPLANES are the A side (m) and the rows the B side (n): the result then has a row of X on
+            // the lane, so the epilogue's look-ups and side bytes of a wave run along consecutive rows.
+            const f16x8 x8 = *(const f16x8 *)(As + (wm * 32 + lr) * SM_LD + blk * 16 + lh * 8);
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                a8[t] = *(const f16x8 *)(As + (wm * 64 + t * 32 + lr) * SM_LD + blk * 16 + lh * 8);
-                b8[t] = *(const f16x8 *)(Bs + (wn * 64 + t * 32 + lr) * SM_LD + blk * 16 + lh * 8);
+            for (int tn = 0; tn < 2; tn++) {
+                const f16x8 h8 = *(const f16x8 *)(Bs + (wn * 64 + tn * 32 + lr) * SM_LD + blk * 16 + lh * 8);
+                acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8, x8, acc[tn], 0, 0, 0);
             }
-#pragma unroll
-            for (int tm = 0; tm < 2; tm++)
-#pragma unroll
-                for (int tn = 0; tn < 2; tn++)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8[tm], b8[tn], acc[tm][tn], 0, 0, 0);
         }
         __syncthreads();
         if (more) stash();
         __syncthreads();
     }
 
-    // epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31 (a hyperplane = a task), row = (e & 3) +
-    // 8 * (e >> 2) + 4 * (lane >> 5).  An entry matters only when the row sits in that task's node.
+    // The result goes to LDS as C[hyperplane][row].  C/D layout of the 32x32 MFMA: n = lane & 31 (a row of X),
+    // m = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (a hyperplane = a task of the level).
 #pragma unroll
-    for (int tn = 0; tn < 2; tn++) {
-        const int cl = wn * 64 + tn * 32 + lr, col = c0 + cl;
-        if (col >= n_tasks) continue;
-        const SplitTask t = tasks[col];
-        const float bound = eps * hn[col];
-        const int32_t *rt = row_task + (int64_t)t.tree * n_items;
-        const int32_t *rp = row_pos + (int64_t)t.tree * n_items;
-        uint8_t *sd = side + (int64_t)t.tree * n_items + t.start;
-        int my_ones = 0;
+    for (int tn = 0; tn < 2; tn++)
 #pragma unroll
-        for (int tm = 0; tm < 2; tm++) {
+        for (int e = 0; e < 16; e++)
+            Cs[(wn * 64 + tn * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * SM_TILE + wm * 32 + lr] = acc[tn][e];
+    __syncthreads();
+
+    // A row needs ONE entry per tree: that of its node.  A wave takes 64 consecutive rows and one tree at a
+    // time: the task look-up, the position look-up and the side bytes all run along consecutive rows.
+    const int c_hi = (c0 + SM_TILE < n_tasks ? c0 + SM_TILE : n_tasks);   // tasks [c0, c_hi) are this tile's
+    const int t_first = s_tree[0], t_last = s_tree[c_hi - 1 - c0];
+    const int64_t row = r0 + (tid & (SM_TILE - 1));
+    const bool row_ok = row < n_items;
+    const float xnr = eps * xn[row_ok ? row : 0];
+    constexpr int EU = 8, TSTEP = SM_THREADS / SM_TILE;   // trees per batch and thread; trees between a thread's steps
+    for (int tb = t_first + (tid >> 7); tb <= t_last; tb += EU * TSTEP) {
+        // the look-ups of a batch are issued together: each one is a dependent chain of two loads
+        int a[EU], pos[EU];
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int64_t row = r0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (row >= n_items || rt[row] != col) continue;
-                const float c = acc[tm][tn][e];
-                if (fabsf(c) > bound * xn[row]) {   // false for NaN and for rows / hyperplanes that could not be scaled
-                    const int s = c > 0.f;
-                    sd[rp[row]] = (uint8_t)s;
-                    my_ones += s;
-                } else {
-                    const unsigned int idx = atomicAdd(amb_count, 1u);
-                    if (idx < amb_cap) amb[idx] = make_int2((int)row, col);
+        for (int u = 0; u < EU; u++) {
+            const int tr = tb + u * TSTEP;
+            a[u] = (row_ok && tr <= t_last) ? row_task[(int64_t)tr * n_items + row] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < EU; u++) {
+            const int tr = tb + u * TSTEP;
+            pos[u] = (a[u] >= c0 && a[u] < c_hi) ? row_pos[(int64_t)tr * n_items + row] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < EU; u++) {
+            const int tr = tb + u * TSTEP;
+            const bool mine = a[u] >= c0 && a[u] < c_hi;
+            const int cl = mine ? a[u] - c0 : 0;
+            const float c = Cs[cl * SM_TILE + (tid & (SM_TILE - 1))];   // bank = row: no conflict whatever the nodes are
+            // false for NaN and for rows / hyperplanes that could not be scaled (norm = +inf)
+            const bool decided = mine && fabsf(c) > xnr * s_hn[cl];
+            const bool one = decided && c > 0.f;
+            if (decided) side[(int64_t)tr * n_items + s_start[cl] + pos[u]] = (uint8_t)one;
+            // right-side counts: one LDS atomic per wave when its rows share the node (the rule at shallow levels)
+            const uint64_t mm = __ballot(mine);
+            if (mm) {
+                const int cl0 = __builtin_amdgcn_readlane(cl, __builtin_ctzll(mm));
+                const uint64_t onem = __ballot(one);
+                if (__ballot(mine && cl != cl0) == 0) {
+                    if (onem && lane == __builtin_ctzll(mm)) atomicAdd(&s_ones[cl0], (int)__builtin_popcountll(onem));
+                } else if (one) {
+                    atomicAdd(&s_ones[cl], 1);
+                }
+            }
+            // open pairs are collected in LDS: all workgroups adding to the ONE global counter pair by pair (or
+            // wave by wave) is what the kernel would otherwise wait for (~350 M same-address atomics per second)
+            const bool open = mine && !decided;
+            const uint64_t om = __ballot(open);
+            if (om) {
+                int base = 0;
+                if (lane == __builtin_ctzll(om)) base = atomicAdd(&s_nopen, (int)__builtin_popcountll(om));
+                base = __builtin_amdgcn_readlane(base, __builtin_ctzll(om));
+                const int idx = base + (int)__builtin_popcountll(om & ((1ull << lane) - 1ull));
+                if (open) {
+                    if (idx < SM_OPEN) {
+                        s_open[idx] = make_int2((int)row, a[u]);
+                    } else {   // more than the LDS list holds: straight to the global list
+                        const unsigned int g = atomicAdd(amb_count, 1u);
+                        if (g < amb_cap) amb[g] = make_int2((int)row, a[u]);
+                    }
                 }
             }
         }
-        if (my_ones) atomicAdd(&s_ones[cl], my_ones);
+    }
+    __syncthreads();
+    {
+        const int n_open = s_nopen < SM_OPEN ? s_nopen : SM_OPEN;
+        if (tid == 0 && n_open) s_obase = atomicAdd(amb_count, (unsigned int)n_open);
+        __syncthreads();
+        for (int i = tid; i < n_open; i += SM_THREADS)
+            if (s_obase + i < amb_cap) amb[s_obase + i] = s_open[i];
     }
     __syncthreads();
     if (tid < SM_TILE && c0 + tid < n_tasks && s_ones[tid]) atomicAdd(&ones[c0 + tid], s_ones[tid]);
@@ -242,7 +302,8 @@ int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, co
     hipLaunchKernelGGL(rows_to_half_kernel, dim3((unsigned)((n_tasks + 3) / 4)), dim3(256), 0, h->stream, hp_level,
                        (int64_t)n_tasks, h->dpad, h16.p, hn.p);
     const dim3 grid((unsigned)((N + SM_TILE - 1) / SM_TILE), (unsigned)((n_tasks + SM_TILE - 1) / SM_TILE));
-    hipLaunchKernelGGL(split_mm_kernel, grid, dim3(256), 0, h->stream, x16.p, xn.p, N, h->dpad, h16.p, hn.p, n_tasks, d_tasks,
+    HIP_TRY(hipFuncSetAttribute((const void *)split_mm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_TILE * SM_TILE * 4));
+    hipLaunchKernelGGL(split_mm_kernel, grid, dim3(SM_THREADS), SM_TILE * SM_TILE * 4, h->stream, x16.p, xn.p, N, h->dpad, h16.p, hn.p, n_tasks, d_tasks,
                        row_task, row_pos, sm_eps(h->dpad), side, ones, amb_count, amb, (unsigned int)cap);
     hipLaunchKernelGGL(split_amb_kernel, dim3((unsigned)(4 * h->n_cus)), dim3(256), 0, h->stream, h->X.p, N, h->dpad, d_tasks,
                        row_pos, seed, hp_level, amb_count, amb, (unsigned int)cap, side, ones);
