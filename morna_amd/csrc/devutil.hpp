@@ -121,6 +121,38 @@ __device__ inline float ang_dist(float pp, float qq, float pq)
     return 2.0f;
 }
 
+// One step of annoy's two_means centroid update for four elements, (c * n + x / |x|) / (n + 1), every
+// operation rounded to fp32 as the scalar code rounds it.  The two quotients are taken through fp64
+// reciprocals, r1 = RN64(1 / |x|), r2 = RN64(1 / (n + 1)): a quotient a / b of two floats is never exactly
+// on, nor within 2^-49 (relative) of, a rounding boundary of float (a - b * mid is a non-zero multiple of
+// ulp(b) * ulp(mid) for every midpoint mid), and RN64(a * RN64(1 / b)) is within 2^-52 of a / b, so its
+// nearest float IS RN32(a / b).  That argument needs a normal float result: the rare results below the
+// normal range are recomputed with real divisions (the branch is wave-uniform).  All 64 lanes must call.
+__device__ inline float4 centroid_step4(const float4 c, const float4 x, float f0, float f1, float norm, double r1,
+                                        double r2)
+{
+    const float tiny = 1.17549435e-38f;   // FLT_MIN
+    const float nx = (float)((double)x.x * r1), ny = (float)((double)x.y * r1);
+    const float nz = (float)((double)x.z * r1), nw = (float)((double)x.w * r1);
+    const float tx = c.x * f0 + nx, ty = c.y * f0 + ny, tz = c.z * f0 + nz, tw = c.w * f0 + nw;
+    float4 o;
+    o.x = (float)((double)tx * r2);
+    o.y = (float)((double)ty * r2);
+    o.z = (float)((double)tz * r2);
+    o.w = (float)((double)tw * r2);
+    const bool sus = (fabsf(nx) < tiny && x.x != 0.f) || (fabsf(ny) < tiny && x.y != 0.f) ||
+                     (fabsf(nz) < tiny && x.z != 0.f) || (fabsf(nw) < tiny && x.w != 0.f) ||
+                     (fabsf(o.x) < tiny && tx != 0.f) || (fabsf(o.y) < tiny && ty != 0.f) ||
+                     (fabsf(o.z) < tiny && tz != 0.f) || (fabsf(o.w) < tiny && tw != 0.f);
+    if (__any(sus)) {
+        o.x = (c.x * f0 + x.x / norm) / f1;
+        o.y = (c.y * f0 + x.y / norm) / f1;
+        o.z = (c.z * f0 + x.z / norm) / f1;
+        o.w = (c.w * f0 + x.w / norm) / f1;
+    }
+    return o;
+}
+
 // order-preserving map float -> uint32 (total order of non-NaN values)
 __device__ inline uint32_t f32_orderable(float f)
 {

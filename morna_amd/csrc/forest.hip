@@ -255,18 +255,16 @@ __global__ __launch_bounds__(256) void two_means_wave_kernel(const float *__rest
         if (norm > 0.f) {
             if (di < dj) {
                 const float f0 = (float)ic, f1 = (float)(ic + 1);
+                const double r1 = 1.0 / (double)norm, r2 = 1.0 / (double)f1;
 #pragma unroll
-                for (int kk = 0; kk < NV; kk++)
-                    EW4(p[kk], (p[kk].x * f0 + x[kk].x / norm) / f1, (p[kk].y * f0 + x[kk].y / norm) / f1,
-                        (p[kk].z * f0 + x[kk].z / norm) / f1, (p[kk].w * f0 + x[kk].w / norm) / f1);
+                for (int kk = 0; kk < NV; kk++) p[kk] = centroid_step4(p[kk], x[kk], f0, f1, norm, r1, r2);
                 pp = reg_dot<NV>(p, p);
                 ic++;
             } else if (dj < di) {
                 const float f0 = (float)jc, f1 = (float)(jc + 1);
+                const double r1 = 1.0 / (double)norm, r2 = 1.0 / (double)f1;
 #pragma unroll
-                for (int kk = 0; kk < NV; kk++)
-                    EW4(q[kk], (q[kk].x * f0 + x[kk].x / norm) / f1, (q[kk].y * f0 + x[kk].y / norm) / f1,
-                        (q[kk].z * f0 + x[kk].z / norm) / f1, (q[kk].w * f0 + x[kk].w / norm) / f1);
+                for (int kk = 0; kk < NV; kk++) q[kk] = centroid_step4(q[kk], x[kk], f0, f1, norm, r1, r2);
                 qq = reg_dot<NV>(q, q);
                 jc++;
             }
@@ -393,15 +391,13 @@ __global__ __launch_bounds__(256) void two_means_quad_kernel(const float *__rest
         if (norm > 0.f) upd = di < dj ? 1 : (dj < di ? 2 : 0);
         if (upd) {
             const float f0 = upd == 1 ? (float)ic : (float)jc, f1 = f0 + 1.f;   // counts are small integers: exact
+            const double r1 = 1.0 / (double)norm, r2 = 1.0 / (double)f1;
 #pragma unroll
             for (int s = 0; s < NS; s++) {
                 const float4 c1 = quad_pick<NV>(p, w, s), c2 = quad_pick<NV>(q, w, s);
-                float4 c, v;
+                float4 c;
                 EW4(c, upd == 1 ? c1.x : c2.x, upd == 1 ? c1.y : c2.y, upd == 1 ? c1.z : c2.z, upd == 1 ? c1.w : c2.w);
-                const float4 xv = xrow[soff + s * WAVE];
-                EW4(v, (c.x * f0 + xv.x / norm) / f1, (c.y * f0 + xv.y / norm) / f1, (c.z * f0 + xv.z / norm) / f1,
-                    (c.w * f0 + xv.w / norm) / f1);
-                cbuf[par][soff + s * WAVE] = v;
+                cbuf[par][soff + s * WAVE] = centroid_step4(c, xrow[soff + s * WAVE], f0, f1, norm, r1, r2);
             }
         }
         __syncthreads();
