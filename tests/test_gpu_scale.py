@@ -181,3 +181,51 @@ def test_edge_cases_small_and_ragged():
     assert (b.get_items() == 0).all()
     b.build(2)
     assert sorted(b.get_nns_by_item(1, 3, -1)) == [0, 1, 2]
+
+
+_FOREST_DIGEST = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from morna_amd.annoy import AnnoyIndex
+rng = np.random.default_rng(20261004)
+N, D, T = 30000, 700, 24
+C = rng.standard_normal((40, D)).astype(np.float32)
+X = (C[rng.integers(0, 40, N)] * rng.uniform(1e-3, 1e3, (N, 1)).astype(np.float32)
+     + 0.4 * rng.standard_normal((N, D)).astype(np.float32)).astype(np.float32)
+X[5] = 0.0
+X[7] = X[6]
+X[11] *= np.float32(1e-30)          # a row far below the fp16 range after scaling fails: its own scale handles it
+a = AnnoyIndex(D)
+a.add_items(X)
+a.build(T)
+f = a.get_forest()
+h = hashlib.sha256()
+for k in ("perm", "node_rec", "hyperplanes", "hp_node"):
+    h.update(np.ascontiguousarray(f[k]).tobytes())
+ids, d, cnt = a.get_nns_by_item_batch(np.arange(64, dtype=np.int32), 10, -1)
+h.update(ids.tobytes()); h.update(d.tobytes())
+print("DIGEST", h.hexdigest(), a.forest_stats()["n_split"], a.forest_stats()["max_depth"])
+"""
+
+
+def test_matrix_core_split_equals_plain_split(tmp_path):
+    """The fp16 MFMA filter + exact fallback (splitmm.hip) must write exactly the sides of the plain fp32
+    kernels: same seeded build in two processes, MORNA_SPLIT_MM=1 (default) and =0 (row-window / chunk forms),
+    rows spanning six orders of magnitude in norm, a zero row, duplicates, a row of denormal scale."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = str(tmp_path / "digest.py")
+    with open(script, "w") as fh:
+        fh.write(_FOREST_DIGEST.format(root=root))
+    out = {}
+    for mm in ("1", "0"):
+        env = dict(os.environ, MORNA_SPLIT_MM=mm)
+        r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0].split()
+        out[mm] = line[1:]
+    assert out["1"] == out["0"], out
+    assert int(out["1"][2]) >= 4                                            # deep enough for every form to run
