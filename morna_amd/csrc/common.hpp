@@ -121,6 +121,7 @@ struct morna_index {
     morna::DevBuf<float> X;      // [n_items][dpad], pad columns zero
     morna::DevBuf<float> norm2;  // [n_items] canonical dot(x, x)
     bool norms_valid = false;
+    bool half_valid = false;     // scratch[19] / [20] hold the fp16 image of X, its norms and scales (splitmm.hip)
 
     // staged junction lines (CSR by line, file order)
     int64_t J = 0, nnz = 0, key_bytes_n = 0;

@@ -275,6 +275,7 @@ int compute_norms(morna_index *h)
         HIP_TRY(hipGetLastError());
     }
     h->norms_valid = true;
+    h->half_valid = false;   // the rows changed: their fp16 image (splitmm.hip) is made again when next needed
     return MORNA_OK;
 }
 

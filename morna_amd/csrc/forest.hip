@@ -853,7 +853,6 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
     std::vector<SplitTask> tasks;
     std::vector<int32_t> h_ones;
     int32_t level = 0;
-    bool half_rows_ready = false;   // fp16 image of the rows (splitmm.hip), made once per build
 
     auto cleanup = [&]() {};
 #define F_TRY(e)                                                    \
@@ -991,10 +990,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             }
             if (use_mm) {
                 ScopedTimer tm(h, MORNA_T_SPLIT, 4 * (int64_t)D * (rows + A));
-                if (!half_rows_ready) {
-                    if ((rc = split_mm_prepare_rows(h))) { cleanup(); return rc; }
-                    half_rows_ready = true;
-                }
+                if ((rc = split_mm_prepare_rows(h))) { cleanup(); return rc; }   // once per set of rows
                 if ((rc = split_mm_level(h, d_tasks.p, A, hp_level, row_task.p, row_pos.p, seed, side.p, d_ones.p))) {
                     cleanup();
                     return rc;

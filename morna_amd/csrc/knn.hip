@@ -47,6 +47,10 @@ struct QueryParams {
     float *dist_out;           // [nq][k]
     int32_t *count_out;        // [nq]
     unsigned long long *stat;  // rows read: hyperplane dots + unique candidates + query
+    // candidate filter on the fp16 image of the rows (splitmm.hip); null: every candidate gets the fp32 dot
+    const _Float16 *X16;       // [n_items][dpad], row r scaled by 2^e(r)
+    const float *xscale;       // [n_items] 2^-e(r)
+    float delta;               // bound on |distance from the fp16 row - distance from the fp32 row|
 };
 
 __device__ inline uint64_t pq_key(float d, int32_t node)
@@ -163,10 +167,75 @@ __global__ __launch_bounds__(Q_THREADS) void query_kernel(QueryParams P)
     // ---- phase 3: angular distance to every unique candidate row
     const int ncand = s_ncand < P.cap ? s_ncand : P.cap;
     const float pp = s_pp;
-    for (int c = w; c < ncand; c += Q_WAVES) {
-        const int32_t id = cand[c];
-        const float pqv = wave_dot((const float4 *)(P.X + (int64_t)id * P.dpad), qv, nvec, lane);
-        if (lane == 0) keys[c] = ((uint64_t)f32_orderable(ang_dist(pp, P.norm2[id], pqv)) << 32) | (uint32_t)id;
+    if (P.X16 && ncand > P.k) {
+        // 3a. FILTER: distances from the fp16 rows (half the bytes of the fp32 rows).  Each is within delta of the
+        // distance phase 3b would compute, so the k smallest exact distances are among the candidates whose
+        // filter distance is at most (k-th smallest filter distance) + 2 delta: only those get the fp32 dot.
+        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+        const int nv8 = P.dpad / 8;
+        for (int c = w; c < ncand; c += Q_WAVES) {
+            const int32_t id = cand[c];
+            const f16x8 *y = (const f16x8 *)(P.X16 + (int64_t)id * P.dpad);
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            auto mac8 = [&](const f16x8 hv, int i) {
+                const float4 qa = qv[2 * i], qb = qv[2 * i + 1];
+                s0 = fmaf((float)hv[0], qa.x, s0);
+                s1 = fmaf((float)hv[1], qa.y, s1);
+                s2 = fmaf((float)hv[2], qa.z, s2);
+                s3 = fmaf((float)hv[3], qa.w, s3);
+                s0 = fmaf((float)hv[4], qb.x, s0);
+                s1 = fmaf((float)hv[5], qb.y, s1);
+                s2 = fmaf((float)hv[6], qb.z, s2);
+                s3 = fmaf((float)hv[7], qb.w, s3);
+            };
+            int i = lane;
+            for (; i + 5 * WAVE < nv8; i += 6 * WAVE) {   // six 1-KiB loads in flight before the first use
+                const f16x8 h0 = y[i], h1 = y[i + WAVE], h2 = y[i + 2 * WAVE], h3 = y[i + 3 * WAVE];
+                const f16x8 h4 = y[i + 4 * WAVE], h5 = y[i + 5 * WAVE];
+                mac8(h0, i);
+                mac8(h1, i + WAVE);
+                mac8(h2, i + 2 * WAVE);
+                mac8(h3, i + 3 * WAVE);
+                mac8(h4, i + 4 * WAVE);
+                mac8(h5, i + 5 * WAVE);
+            }
+            for (; i < nv8; i += WAVE) mac8(y[i], i);
+            const float sc = P.xscale[id];   // 0: the row has no fp16 image (inf, NaN or below the scalable range)
+            const float dotf = wave_sum_xor((s0 + s1) + (s2 + s3)) * sc;
+            // such a row gets NaN: it sorts after every number, so it takes none of the k places that set the
+            // threshold, and it passes the test of 3b
+            const float df = sc != 0.f ? ang_dist(pp, P.norm2[id], dotf) : __int_as_float(0x7fc00000);
+            if (lane == 0) keys[c] = ((uint64_t)f32_orderable(df) << 32) | (uint32_t)c;
+        }
+        __syncthreads();
+        uint64_t kth = 0;   // the k-th smallest filter key (keys are distinct: the candidate index is in them)
+        for (int r = 0; r < P.k; r++) {
+            uint64_t best = ~0ull;
+            for (int c = tid; c < ncand; c += Q_THREADS) {
+                const uint64_t kk = keys[c];
+                if ((r == 0 || kk > kth) && kk < best) best = kk;
+            }
+            kth = block_min_u64(best, s_red, tid);
+        }
+        const float thr = f32_from_orderable((uint32_t)(kth >> 32)) + 2.f * P.delta;
+        __syncthreads();
+        // 3b. the fp32 canonical dot for the survivors; the others can no longer be selected
+        for (int c = w; c < ncand; c += Q_WAVES) {
+            const float df = f32_from_orderable((uint32_t)(keys[c] >> 32));
+            uint64_t key = ~0ull;
+            if (!(df > thr)) {   // NaN stays in
+                const int32_t id = cand[c];
+                const float pqv = wave_dot((const float4 *)(P.X + (int64_t)id * P.dpad), qv, nvec, lane);
+                key = ((uint64_t)f32_orderable(ang_dist(pp, P.norm2[id], pqv)) << 32) | (uint32_t)id;
+            }
+            if (lane == 0) keys[c] = key;
+        }
+    } else {
+        for (int c = w; c < ncand; c += Q_WAVES) {
+            const int32_t id = cand[c];
+            const float pqv = wave_dot((const float4 *)(P.X + (int64_t)id * P.dpad), qv, nvec, lane);
+            if (lane == 0) keys[c] = ((uint64_t)f32_orderable(ang_dist(pp, P.norm2[id], pqv)) << 32) | (uint32_t)id;
+        }
     }
     __syncthreads();
 
@@ -240,6 +309,11 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
                  s_ids = align_up((size_t)batch * k * 4, 256), s_cnt = align_up((size_t)batch * 4, 256);
     MORNA_TRY(h->ws.alloc(s_pq + s_keys + s_q + s_cand + s_bm + 2 * s_ids + s_cnt));
     MORNA_TRY(h->d_stat.alloc(4));
+    // candidate filter on the fp16 rows (MORNA_QUERY_FILTER=0: every candidate gets the fp32 dot); pays when a
+    // query has many more candidates than results
+    static const bool filter_on = !(getenv("MORNA_QUERY_FILTER") && atoi(getenv("MORNA_QUERY_FILTER")) == 0);
+    const bool use_filter = filter_on && cap > 4 * (int64_t)k;
+    if (use_filter) MORNA_TRY(split_mm_prepare_rows(h));
     DevBuf<int32_t> d_items;
     if (items_host) MORNA_TRY(d_items.alloc((size_t)batch));
 
@@ -260,6 +334,15 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
         P.dist_out = (float *)p; p += s_ids;
         P.count_out = (int32_t *)p; p += s_cnt;
         P.stat = h->d_stat.p;
+        P.X16 = nullptr; P.xscale = nullptr; P.delta = 0.f;
+        if (use_filter) {
+            P.X16 = (const _Float16 *)h->scratch[19].p;
+            P.xscale = (const float *)h->scratch[20].p + N;
+            // |cos from the fp16 row - cos from the fp32 row| <= 2^-11 (one rounding to 11 bits, the query is not
+            // rounded) + the fp32 accumulations of both dots (any order: < dpad * 2^-24 each); the distance is
+            // 2 - 2 cos; 1e-5 covers the evaluation of ang_dist itself
+            P.delta = 2.f * (1.02f * 0.00048828125f + 2.f * (float)h->dpad * 5.9604645e-8f) + 1e-5f;
+        }
         P.Q = nullptr; P.items = nullptr;
         if (q_host) {
             HIP_TRY(hipMemsetAsync(Qd, 0, (size_t)nb * h->dpad * 4, h->stream));

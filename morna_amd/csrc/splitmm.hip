@@ -32,7 +32,8 @@ static inline float sm_eps(int32_t dpad) { return 1.02f * 0.0009765625f + 4.f * 
 // Euclidean norm of the fp16 row (+inf when the row cannot be scaled into range: it is then never
 // decided by the filter).
 __global__ __launch_bounds__(256) void rows_to_half_kernel(const float *__restrict__ src, int64_t rows, int32_t dpad,
-                                                           _Float16 *__restrict__ dst, float *__restrict__ norm)
+                                                           _Float16 *__restrict__ dst, float *__restrict__ norm,
+                                                           float *__restrict__ inv_scale /* 2^-e per row, or null */)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const int64_t r = (int64_t)blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
@@ -66,7 +67,10 @@ __global__ __launch_bounds__(256) void rows_to_half_kernel(const float *__restri
     }
     sum = wave_sum_xor(sum);
     // fp32 sum of <= 8192 squares: relative error < 1e-3; the bound is widened by that much
-    if (lane == 0) norm[r] = bad ? INFINITY : sqrtf(sum) * 1.002f;
+    if (lane == 0) {
+        norm[r] = bad ? INFINITY : sqrtf(sum) * 1.002f;
+        if (inv_scale) inv_scale[r] = bad ? 0.f : ldexpf(1.f, -e);
+    }
 }
 
 // ---- the contraction with the side decision fused into its epilogue --------------------------------
@@ -271,13 +275,15 @@ __global__ __launch_bounds__(256) void split_amb_kernel(const float *__restrict_
 // the open-pair list (first 16 bytes: its counter)
 int split_mm_prepare_rows(morna_index *h)
 {
+    if (h->half_valid) return MORNA_OK;
     ScratchRef<_Float16> x16(h->scratch[19]);
-    ScratchRef<float> xn(h->scratch[20]);
+    ScratchRef<float> xn(h->scratch[20]);   // [0, N): norms; [N, 2N): 2^-e per row (the query filter unscales with it)
     MORNA_TRY(x16.alloc((size_t)h->n_items * h->dpad));
-    MORNA_TRY(xn.alloc((size_t)h->n_items));
+    MORNA_TRY(xn.alloc((size_t)h->n_items * 2));
     hipLaunchKernelGGL(rows_to_half_kernel, dim3((unsigned)((h->n_items + 3) / 4)), dim3(256), 0, h->stream, h->X.p,
-                       h->n_items, h->dpad, x16.p, xn.p);
+                       h->n_items, h->dpad, x16.p, xn.p, xn.p + h->n_items);
     HIP_TRY(hipGetLastError());
+    h->half_valid = true;
     return MORNA_OK;
 }
 
@@ -300,7 +306,7 @@ int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, co
     int2 *amb = (int2 *)(ambuf.p + 16);
     HIP_TRY(hipMemsetAsync(amb_count, 0, 16, h->stream));
     hipLaunchKernelGGL(rows_to_half_kernel, dim3((unsigned)((n_tasks + 3) / 4)), dim3(256), 0, h->stream, hp_level,
-                       (int64_t)n_tasks, h->dpad, h16.p, hn.p);
+                       (int64_t)n_tasks, h->dpad, h16.p, hn.p, (float *)nullptr);
     const dim3 grid((unsigned)((N + SM_TILE - 1) / SM_TILE), (unsigned)((n_tasks + SM_TILE - 1) / SM_TILE));
     HIP_TRY(hipFuncSetAttribute((const void *)split_mm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_TILE * SM_TILE * 4));
     hipLaunchKernelGGL(split_mm_kernel, grid, dim3(SM_THREADS), SM_TILE * SM_TILE * 4, h->stream, x16.p, xn.p, N, h->dpad, h16.p, hn.p, n_tasks, d_tasks,
