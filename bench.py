@@ -12,9 +12,9 @@ morna's default search_k=100).  Default workload = BASELINE.json configs[2]:
 by an RCCL all-gather of the per-shard top-k (no other collective on the path).
 
 Prints ONE JSON line (rank 0).  `value` = samples indexed per second over the
-whole step (build + queries), all ranks.  `roofline` is for the dominant kernel,
-the forest split kernel (hyperplane dot + side of every row of every split
-node): algorithmic bytes 4*D*(sum|node| + #nodes) per launch over
+whole step (build + queries), all ranks.  `roofline` is for the kernel group
+that takes the most time (`rooflines` has all four): algorithmic bytes
+ -- or, for the split on the matrix cores, flops -- per launch over
 its HIP-event time on the library's own stream.  `cpu_baseline` times the CPU
 oracle (faithful single-thread restatement of morna + annoy) on a bounded sample
 of the same workload and extrapolates to the full step.
@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-L2_PEAK_GBS = 34500.0   # aggregate L2 read rate of the 8 XCDs (MI355X_MICROARCH.md)
+MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -247,20 +247,54 @@ def main():
 
     out = None
     if rank == 0:
-        sp = timers["split"]
-        achieved = (sp["bytes"] / 1e9) / (sp["ms"] / 1e3) if sp["ms"] > 0 else 0.0
-        # HBM-side bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes
-        # (scripts/profile_summary.py -> profiles/*_traffic.json); only quoted for the same workload
-        traffic, traffic_src = None, None
+        # One roofline entry per kernel group, from the HIP-event timers of the library (events recorded on the
+        # stream the kernels run on) and the algorithmic bytes of SURVEY.md 8(d) that the library counts per launch.
+        # The split group runs on the matrix cores: it is priced in flops (2 * D per row and split node of the
+        # fp32 formulation) against the dense fp16 MFMA peak; `executed_tflops` is what its contraction really does.
+        kernels_of = {"features": ("morna::accumulate_kernel", "morna::transpose_convert_kernel", "morna::hash_keys_kernel",
+                                   "morna::col_fill_kernel", "morna::line_flags_kernel", "morna::row_norms_kernel"),
+                      "two_means": ("morna::two_means",), "split": ("morna::split_", "morna::rows_to_half", "morna::invert_kernel"),
+                      "partition": ("morna::partition_kernel",), "query": ("morna::query_kernel",)}
+        tj = None
         tpath = os.path.join(ROOT, "profiles", "r01_c3_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
-            ks = [v for k, v in tj["kernels"].items() if k.startswith(("morna::split_kernel", "morna::split_rw_kernel"))]
             cfg = tj.get("config", {})
-            if (cfg.get("samples"), cfg.get("features"), cfg.get("trees")) == (N, D, T) and ks:
-                traffic = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in ks) / max(sum(v["calls"] for v in ks), 1)
-                traffic_src = "profiles/r01_c3_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+            if (cfg.get("samples"), cfg.get("features"), cfg.get("trees")) != (N, D, T):
+                tj = None   # HBM-side bytes are only quoted for the workload they were measured on
+
+        def group(name):
+            tm = timers[name]
+            if tm["ms"] <= 0:
+                return None
+            launches = max(tm["launches"], 1)
+            gbs = (tm["bytes"] / 1e9) / (tm["ms"] / 1e3)
+            g = {"kernel": name, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": gbs / HBM_PEAK_GBS, "launches": tm["launches"] // max(args.steps, 1),
+                 "alg_bytes_per_launch": tm["bytes"] // launches, "ms_per_launch": tm["ms"] / launches,
+                 "traffic": None}
+            if name == "split":
+                flops = 2.0 * D * (st["split_rows"] + st["n_split"]) * args.steps      # one dot per row and split node
+                tf = flops / 1e12 / (tm["ms"] / 1e3)
+                executed = 2.0 * n_items * st["n_split"] * D * args.steps             # every row x every hyperplane of its level
+                g.update(bound="mfma", achieved=tf, peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / MFMA_F16_PEAK_TFLOPS,
+                         executed_tflops=executed / 1e12 / (tm["ms"] / 1e3))
+            if tj:
+                ks = [v for k, v in tj["kernels"].items() if k.startswith(kernels_of[name])]
+                if ks:   # bytes past L2 per timed launch group, from separate rocprofv3 --pmc passes
+                    g["traffic"] = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in ks) / max(tm["launches"] // max(args.steps, 1), 1)
+                    g["traffic_source"] = "profiles/r01_c3_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+            return g
+        groups = {n: group(n) for n in ("features", "two_means", "split", "query")}
+        groups = {n: g for n, g in groups.items() if g}
+        dominant = max(groups, key=lambda n: timers[n]["ms"])
+        notes = {"two_means": "one chain of 200 dependent steps per split node (annoy's two_means): bound by the latency of "
+                              "that chain at shallow levels and by VALU issue at deep ones; its rows are gathered at random",
+                 "split": "a level's sides as one fp16 MFMA contraction that filters + exact fp32 dots for the ~1% it leaves open",
+                 "features": "fp64 accumulation in file order in LDS tiles; the nnz stream is read once per sample tile",
+                 "query": "candidate rows gathered at random: fp16 filter pass, fp32 for the survivors"}
+        roofline = dict(groups[dominant], note=notes[dominant])
         total_samples = n_items * world * args.steps
         out = {
             "metric": "samples indexed/sec (index build + %d queries, k=%d) at %dk x %d" % (Q, k, N // 1000, D),
@@ -285,19 +319,8 @@ def main():
             "forest": {"n_nodes": st["n_nodes"], "n_split": st["n_split"], "max_depth": st["max_depth"],
                        "split_rows": st["split_rows"], "split_attempts": st["split_attempts"],
                        "fallback_nodes": st["fallback_nodes"]},
-            "roofline": {"kernel": "split_kernel (+ split_rw_kernel, its row-window form at the three shallowest levels)",
-                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "launches": sp["launches"] // max(args.steps, 1),
-                         "alg_bytes_per_launch": sp["bytes"] // max(sp["launches"], 1),
-                         "ms_per_launch": sp["ms"] / max(sp["launches"], 1),
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         # the level that actually binds this kernel: the same bytes against the aggregate L2 rate
-                         "cache_level": {"bound": "l2", "achieved": achieved, "peak": L2_PEAK_GBS, "unit": "GB/s",
-                                         "frac": achieved / L2_PEAK_GBS},
-                         "note": ("every row is needed once per tree per level; chunks are launched sorted by row id, "
-                                  "one run per XCD, so most of those reads are served by L2: frac > 1 means the "
-                                  "algorithmic bytes exceeded what HBM alone could deliver")},
+            "roofline": roofline,
+            "rooflines": groups,
         }
         if args.verify:
             ids = res[0]

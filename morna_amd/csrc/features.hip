@@ -73,7 +73,7 @@ __global__ __launch_bounds__(1024) void col_scan_kernel(const int32_t *__restric
     if (tid == 1023) off[dim] = s_part[1023];
 }
 
-#define ACC_THREADS 256
+#define ACC_THREADS 1024
 
 // one workgroup per column: ordered list of the lines that hash to it
 __global__ __launch_bounds__(ACC_THREADS) void col_fill_kernel(const int32_t *__restrict__ col, int64_t J,
@@ -140,10 +140,10 @@ __global__ __launch_bounds__(256) void line_flags_kernel(const int64_t *__restri
 
 #define ACC_TILE 8192     // samples per tile: 64 KiB of fp64 accumulators in LDS
 #define ACC_LINES 256     // lines whose extents are staged per pass
-#define ACC_PF 8          // entries per thread prefetched from the next line
+#define ACC_PF 2          // entries per thread prefetched from the next line
 
 __global__ __launch_bounds__(ACC_THREADS) void accumulate_kernel(
-    const int32_t *__restrict__ col_off, const int32_t *__restrict__ col_lines, const double *__restrict__ sidf,
+    int32_t n_tiles, int32_t n_cols, const int32_t *__restrict__ col_off, const int32_t *__restrict__ col_lines, const double *__restrict__ sidf,
     const uint8_t *__restrict__ flags, const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ ids,
     const int32_t *__restrict__ cov, int64_t n_items, double *__restrict__ colacc /* [D][n_items] */)
 {
@@ -151,8 +151,11 @@ __global__ __launch_bounds__(ACC_THREADS) void accumulate_kernel(
     __shared__ int64_t s_b[ACC_LINES], s_e[ACC_LINES];
     __shared__ double s_w[ACC_LINES];
     __shared__ uint8_t s_f[ACC_LINES];
-    const int c = blockIdx.y;
-    const int64_t r_lo = (int64_t)blockIdx.x * ACC_TILE;
+    // block b = ((column / 8) * n_tiles + tile) * 8 + column % 8
+    const int c = (int)(blockIdx.x >> 3) / n_tiles * 8 + (int)(blockIdx.x & 7);
+    const int tile = (int)(blockIdx.x >> 3) % n_tiles;
+    if (c >= n_cols) return;
+    const int64_t r_lo = (int64_t)tile * ACC_TILE;
     const int64_t r_hi = r_lo + ACC_TILE < n_items ? r_lo + ACC_TILE : n_items;
     const uint32_t span = (uint32_t)(r_hi - r_lo);
     const int tid = threadIdx.x;
@@ -372,8 +375,11 @@ int build_features(morna_index *h, int64_t n_items)
         hipLaunchKernelGGL(col_scan_kernel, dim3(1), dim3(1024), 0, h->stream, col_count.p, D, col_off.p);
         hipLaunchKernelGGL(col_fill_kernel, dim3(D), dim3(ACC_THREADS), 0, h->stream, col.p, J, col_off.p, col_lines.p);
         const unsigned tiles = (unsigned)((n_items + ACC_TILE - 1) / ACC_TILE);
-        hipLaunchKernelGGL(accumulate_kernel, dim3(tiles, D), dim3(ACC_THREADS), 0, h->stream, col_off.p, col_lines.p,
-                           sidf.p, flags.p, h->s_row_ptr.p, h->s_ids.p, h->s_cov.p, n_items, colacc.p);
+        // workgroup b runs on XCD b % 8: the sample tiles of one column are dealt to ONE XCD, back to back, so the
+        // column's lines come from HBM once and from that XCD's L2 for the other tiles
+        hipLaunchKernelGGL(accumulate_kernel, dim3(8u * tiles * (unsigned)((D + 7) / 8)), dim3(ACC_THREADS), 0, h->stream,
+                           (int32_t)tiles, (int32_t)D, col_off.p, col_lines.p, sidf.p, flags.p, h->s_row_ptr.p, h->s_ids.p,
+                           h->s_cov.p, n_items, colacc.p);
         dim3 tg((unsigned)((n_items + TT - 1) / TT), (unsigned)((h->dpad + TT - 1) / TT));
         hipLaunchKernelGGL(transpose_convert_kernel, tg, dim3(256), 0, h->stream, colacc.p, n_items, D, h->dpad,
                            h->X.p);

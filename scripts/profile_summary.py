@@ -24,6 +24,10 @@ def per_kernel(path):
     with open(path) as fh:
         for r in csv.DictReader(fh):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            if k.startswith("_ZN5morna"):   # a name rocprofv3 left mangled: _ZN5morna<len><name>...
+                rest = k[len("_ZN5morna"):]
+                digits = "".join(ch for ch in rest[:3] if ch.isdigit())
+                k = "morna::" + rest[len(digits):len(digits) + int(digits)]
             a = agg[k]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
