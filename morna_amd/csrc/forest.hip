@@ -239,16 +239,19 @@ __global__ __launch_bounds__(256) void two_means_wave_kernel(const float *__rest
     uint32_t k = rng.index((uint32_t)t.count);
     int32_t it = items[k];
     reg_load_row<NV>(X + (int64_t)it * dpad, nvec, lane, x);
+    // The Kiss32 stream does not depend on data: the INDEX of row l+2 and the norm of row l+1 are requested a step
+    // before row l+1 itself, so that row's load never waits for its index (two dependent HBM round trips per step
+    // otherwise bound the deep levels).  Draws past step 199 are never used: the stream is the node's own.
+    int32_t it_n1 = items[rng.index((uint32_t)t.count)];
+    float nk2 = norm2[it];
 
     int ic = 1, jc = 1;
     for (int l = 0; l < TM_ITERS; l++) {
         const bool more = l + 1 < TM_ITERS;
-        int32_t it_next = it;
-        if (more) {   // the Kiss32 stream does not depend on data: fetch row l+1 while row l is used
-            it_next = items[rng.index((uint32_t)t.count)];
-            reg_load_row<NV>(X + (int64_t)it_next * dpad, nvec, lane, xn);
-        }
-        const float nk2 = norm2[it];
+        const int32_t it_next = it_n1;
+        if (more) reg_load_row<NV>(X + (int64_t)it_next * dpad, nvec, lane, xn);   // row l+1 while row l is used
+        it_n1 = items[rng.index((uint32_t)t.count)];                                // index of row l+2
+        const float nk2_next = norm2[it_next];
         const float di = (float)ic * ang_dist(pp, nk2, reg_dot<NV>(p, x));
         const float dj = (float)jc * ang_dist(qq, nk2, reg_dot<NV>(q, x));
         const float norm = sqrtf(nk2);
@@ -273,6 +276,7 @@ __global__ __launch_bounds__(256) void two_means_wave_kernel(const float *__rest
 #pragma unroll
             for (int kk = 0; kk < NV; kk++) x[kk] = xn[kk];
             it = it_next;
+            nk2 = nk2_next;
         }
     }
     // create_split: n = normalize(p - q)
