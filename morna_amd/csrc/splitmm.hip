@@ -77,7 +77,6 @@ __global__ __launch_bounds__(256) void rows_to_half_kernel(const float *__restri
 #define SM_TILE 128
 #define SM_THREADS 512           // 8 waves, each a 32 x 64 part of the tile: four workgroups per CU cover each other's loads
 #define SM_BK 64                 // halfs per K step
-#define SM_LD (SM_BK + 8)        // 144-byte LDS rows: 16-byte accesses stay aligned, rows fall on different banks
 #define SM_OPEN 1536             // open pairs a tile keeps in LDS (12 KB; ~500 expected of 16384 at the root level)
 
 __global__ __launch_bounds__(SM_THREADS) void split_mm_kernel(
@@ -87,10 +86,9 @@ __global__ __launch_bounds__(SM_THREADS) void split_mm_kernel(
     float eps, uint8_t *__restrict__ side, int32_t *__restrict__ ones, unsigned int *__restrict__ amb_count,
     int2 *__restrict__ amb, unsigned int amb_cap)
 {
-    // 64 KB: during the contraction the two operand slabs, afterwards the 128 x 128 result
+    // 64 KB: during the contraction two buffers of two operand slabs ([128 rows][64 halfs] each), afterwards
+    // the 128 x 128 result
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    _Float16 *As = (_Float16 *)smem;              // rows        [128][72]
-    _Float16 *Bs = As + SM_TILE * SM_LD;          // hyperplanes [128][72]
     float *Cs = (float *)smem;                    // result      [128 hyperplanes][128 rows]
     __shared__ int s_ones[SM_TILE], s_tree[SM_TILE], s_start[SM_TILE];
     __shared__ float s_hn[SM_TILE];
@@ -102,22 +100,28 @@ __global__ __launch_bounds__(SM_THREADS) void split_mm_kernel(
     const int64_t r0 = (int64_t)blockIdx.x * SM_TILE;
     const int c0 = (int)blockIdx.y * SM_TILE;
 
-    uint4 ga[2], gb[2];
-    auto fetch = [&](int k0) {
+    // Operand slabs go from global memory straight into LDS (global_load_lds_dwordx4: no staging registers, no
+    // ds_write -- the VGPR -> LDS store path, ~80 B/clk, would take as long as the slab's MFMAs).  One wave
+    // instruction fills 1 KiB of LDS = 8 tile rows of 128 B, lane i at byte 16 i.  The image is unpadded, so the
+    // 16-byte chunks of row r are XOR-swizzled with (r >> 1) & 7: lane i fetches chunk (i & 7) ^ f(row) of its
+    // row, a reader finds chunk c of row r at position c ^ f(r), and the 16 lanes ds_read_b128 serves per cycle
+    // (rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of a 32-row fragment) fall on 16 different bank groups.
+    // Two buffers: the slab of step k+1 lands while step k is multiplied; one barrier per step.
+    auto dma = [&](int k0, int buf) {
 #pragma unroll
-        for (int it = 0; it < 2; it++) {
-            const int idx = tid + it * SM_THREADS, row = idx >> 3, c8 = idx & 7;   // 8 x 16 bytes = 64 halfs per row
-            ga[it] = r0 + row < n_items ? *(const uint4 *)(X16 + (r0 + row) * dpad + k0 + c8 * 8) : make_uint4(0, 0, 0, 0);
-            gb[it] = c0 + row < n_tasks ? *(const uint4 *)(H16 + (int64_t)(c0 + row) * dpad + k0 + c8 * 8)
-                                        : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto stash = [&]() {
-#pragma unroll
-        for (int it = 0; it < 2; it++) {
-            const int idx = tid + it * SM_THREADS, row = idx >> 3, c8 = idx & 7;
-            *(uint4 *)(As + row * SM_LD + c8 * 8) = ga[it];
-            *(uint4 *)(Bs + row * SM_LD + c8 * 8) = gb[it];
+        for (int u = 0; u < 4; u++) {
+            const int j = w * 4 + u;                       // 32 instructions per step: 16 for the rows, 16 for the hyperplanes
+            const bool is_x = j < 16;
+            const int rt = ((is_x ? j : j - 16) << 3) + (lane >> 3);   // row of the tile
+            const int chunk = (lane & 7) ^ ((rt >> 1) & 7);
+            // rows past the end repeat the last one: their products are never looked up
+            const int64_t gx = r0 + rt < n_items ? r0 + rt : n_items - 1;
+            const int64_t gh = c0 + rt < n_tasks ? c0 + rt : n_tasks - 1;
+            const _Float16 *src = (is_x ? X16 + gx * dpad : H16 + gh * dpad) + k0 + chunk * 8;
+            unsigned char *dst = smem + buf * (2 * SM_TILE * SM_BK * 2) + (is_x ? 0 : SM_TILE * SM_BK * 2) +
+                                 (is_x ? j : j - 16) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
     };
     f32x16 acc[2];
@@ -135,27 +139,31 @@ __global__ __launch_bounds__(SM_THREADS) void split_mm_kernel(
         s_hn[tid] = hn[col];
     }
 
-    fetch(0);
-    stash();
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int lr = lane & 31, lh = lane >> 5;
-    for (int k0 = 0; k0 < dpad; k0 += SM_BK) {
-        const bool more = k0 + SM_BK < dpad;
-        if (more) fetch(k0 + SM_BK);   // next K slab in flight under the MFMAs
+    const int xrow = wm * 32 + lr, xsw = (xrow >> 1) & 7;
+    for (int k0 = 0, buf = 0; k0 < dpad; k0 += SM_BK, buf ^= 1) {
+        if (k0 + SM_BK < dpad) dma(k0 + SM_BK, buf ^ 1);   // next slab lands in the other buffer under the MFMAs
+        const unsigned char *xs = smem + buf * (2 * SM_TILE * SM_BK * 2);
+        const unsigned char *hs = xs + SM_TILE * SM_BK * 2;
 #pragma unroll
         for (int blk = 0; blk < SM_BK / 16; blk++) {
-            // 32x32x16: lane (r = l & 31, h = l >> 5) supplies A[m = r][k = 8h + j], B[k = 8h + j][n = r], j = 0..7.
-            // The HYPERPLANES are the A side (m) and the rows the B side (n): the result then has a row of X on
-            // the lane, so the epilogue's look-ups and side bytes of a wave run along consecutive rows.
-            const f16x8 x8 = *(const f16x8 *)(As + (wm * 32 + lr) * SM_LD + blk * 16 + lh * 8);
+            // 32x32x16: lane (r = l & 31, h = l >> 5) supplies A[m = r][k = 8h + j], B[k = 8h + j][n = r], j = 0..7,
+            // i.e. the 16-byte chunk 2 blk + h of its row.  The HYPERPLANES are the A side (m) and the rows the B
+            // side (n): the result then has a row of X on the lane, so the epilogue's look-ups and side bytes of a
+            // wave run along consecutive rows.
+            const int kc = 2 * blk + lh;
+            const f16x8 x8 = *(const f16x8 *)(xs + xrow * 128 + ((kc ^ xsw) << 4));
 #pragma unroll
             for (int tn = 0; tn < 2; tn++) {
-                const f16x8 h8 = *(const f16x8 *)(Bs + (wn * 64 + tn * 32 + lr) * SM_LD + blk * 16 + lh * 8);
+                const int hrow = wn * 64 + tn * 32 + lr;
+                const f16x8 h8 = *(const f16x8 *)(hs + hrow * 128 + ((kc ^ ((hrow >> 1) & 7)) << 4));
                 acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8, x8, acc[tn], 0, 0, 0);
             }
         }
-        __syncthreads();
-        if (more) stash();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the next slab is in LDS
         __syncthreads();
     }
 
