@@ -856,9 +856,11 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
     int rc = MORNA_OK;
     std::vector<SplitTask> tasks;
     std::vector<int32_t> h_ones;
+    std::vector<std::vector<SplitTask>> kept_tasks;   // host arguments of launches the host did not wait for
+    std::vector<std::vector<int32_t>> kept_ones;
     int32_t level = 0;
 
-    auto cleanup = [&]() {};
+    auto cleanup = [&]() { (void)hipStreamSynchronize(h->stream); };   // kept host arguments may still be in flight
 #define F_TRY(e)                                                    \
     do {                                                            \
         hipError_t _e = (e);                                        \
@@ -879,7 +881,8 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
         const int32_t S = (int32_t)split_idx.size();
         {
             const size_t need = (size_t)(n_split_total + S) * dpad;
-            if (need > h->hp.n) {   // the stream is idle here (synchronised at the end of the previous level)
+            if (need > h->hp.n) {
+                F_TRY(hipStreamSynchronize(h->stream));   // the previous level's partition may still be running
                 DevBuf<float> bigger;
                 if ((rc = bigger.alloc(std::max(need, h->hp.n * 2)))) return rc;
                 if (n_split_total > 0)
@@ -1075,15 +1078,19 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
         {
             std::vector<int32_t> all((size_t)S);
             for (int32_t i = 0; i < S; i++) all[(size_t)i] = i;
-            make_tasks(all, 0, tasks);
-            F_TRY(hipMemcpyAsync(d_tasks.p, tasks.data(), (size_t)S * sizeof(SplitTask), hipMemcpyHostToDevice, h->stream));
-            F_TRY(hipMemcpyAsync(d_ones.p, final_ones.data(), (size_t)S * 4, hipMemcpyHostToDevice, h->stream));
+            // The host does not wait for the partition: the next level's tasks follow from the counts it already
+            // has, and everything it enqueues is ordered behind the partition on the stream.  The host copies of
+            // this launch's arguments are therefore kept (not reused) until the build's final synchronisation.
+            kept_tasks.emplace_back();
+            kept_ones.push_back(final_ones);
+            make_tasks(all, 0, kept_tasks.back());
+            F_TRY(hipMemcpyAsync(d_tasks.p, kept_tasks.back().data(), (size_t)S * sizeof(SplitTask), hipMemcpyHostToDevice, h->stream));
+            F_TRY(hipMemcpyAsync(d_ones.p, kept_ones.back().data(), (size_t)S * 4, hipMemcpyHostToDevice, h->stream));
             ScopedTimer tm(h, MORNA_T_PARTITION, 0);
             hipLaunchKernelGGL(partition_kernel, dim3((unsigned)S), dim3(256), 0, h->stream, d_tasks.p, N, side.p,
                                d_ones.p, h->perm.p, tmp.p);
         }
         F_TRY(hipGetLastError());
-        F_TRY(hipStreamSynchronize(h->stream));   // tasks / final_ones host buffers are reused next level
 
         // children: ids base + 2*i + side for the i-th split node of the level
         nxt.clear();
