@@ -196,6 +196,11 @@ X = (C[rng.integers(0, 40, N)] * rng.uniform(1e-3, 1e3, (N, 1)).astype(np.float3
 X[5] = 0.0
 X[7] = X[6]
 X[11] *= np.float32(1e-30)          # a row far below the fp16 range after scaling fails: its own scale handles it
+# 600 rows that differ from row 50 in the 4th digit: for queries among them, hundreds of candidates lie within
+# the filter's 2 * delta of the k-th distance and must all reach the fp32 ranking
+X[1000:1600] = X[50] * (1.0 + 1e-4 * rng.standard_normal((600, D))).astype(np.float32)
+X[1600:1700] = X[50] * np.float32(3.0)                      # exact scaled duplicates: ties broken by id
+X[13, 0] = np.float32(np.inf)                               # a row with no fp16 image at all
 a = AnnoyIndex(D)
 a.add_items(X)
 a.build(T)
@@ -203,16 +208,21 @@ f = a.get_forest()
 h = hashlib.sha256()
 for k in ("perm", "node_rec", "hyperplanes", "hp_node"):
     h.update(np.ascontiguousarray(f[k]).tobytes())
-ids, d, cnt = a.get_nns_by_item_batch(np.arange(64, dtype=np.int32), 10, -1)
-h.update(ids.tobytes()); h.update(d.tobytes())
+items = np.concatenate([np.arange(64), np.arange(1000, 1064), np.arange(1600, 1616), [13]]).astype(np.int32)
+for n, sk in ((10, -1), (40, 100), (3, 5000)):
+    ids, d, cnt = a.get_nns_by_item_batch(items, n, sk)
+    h.update(ids.tobytes()); h.update(d.tobytes()); h.update(cnt.tobytes())
 print("DIGEST", h.hexdigest(), a.forest_stats()["n_split"], a.forest_stats()["max_depth"])
 """
 
 
-def test_matrix_core_split_equals_plain_split(tmp_path):
-    """The fp16 MFMA filter + exact fallback (splitmm.hip) must write exactly the sides of the plain fp32
-    kernels: same seeded build in two processes, MORNA_SPLIT_MM=1 (default) and =0 (row-window / chunk forms),
-    rows spanning six orders of magnitude in norm, a zero row, duplicates, a row of denormal scale."""
+def test_filters_do_not_change_results(tmp_path):
+    """The fp16 MFMA split filter + exact fallback (splitmm.hip) must write exactly the sides of the plain fp32
+    kernels, and the fp16 candidate filter of the approximate search must return exactly what the all-fp32
+    search returns: the same seeded build and searches in three processes -- defaults, MORNA_SPLIT_MM=0
+    (row-window / chunk forms), MORNA_QUERY_FILTER=0 -- on rows spanning six orders of magnitude in norm, a zero
+    row, duplicates, near-duplicates in the 4th digit, exact scaled duplicates, a row of denormal scale and a row
+    holding an infinity."""
     import os
     import subprocess
     import sys
@@ -221,11 +231,11 @@ def test_matrix_core_split_equals_plain_split(tmp_path):
     with open(script, "w") as fh:
         fh.write(_FOREST_DIGEST.format(root=root))
     out = {}
-    for mm in ("1", "0"):
-        env = dict(os.environ, MORNA_SPLIT_MM=mm)
+    for name, extra in (("default", {}), ("no_mm", {"MORNA_SPLIT_MM": "0"}), ("no_qf", {"MORNA_QUERY_FILTER": "0"})):
+        env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0].split()
-        out[mm] = line[1:]
-    assert out["1"] == out["0"], out
-    assert int(out["1"][2]) >= 4                                            # deep enough for every form to run
+        out[name] = line[1:]
+    assert out["default"] == out["no_mm"] == out["no_qf"], out
+    assert int(out["default"][2]) >= 4                                      # deep enough for every form to run
