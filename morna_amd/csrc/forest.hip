@@ -740,19 +740,20 @@ __global__ __launch_bounds__(256) void fallback_kernel(const SplitTask *__restri
     }
 }
 
-// stable partition of one segment by side; one workgroup per node
-__global__ __launch_bounds__(256) void partition_kernel(const SplitTask *__restrict__ tasks, int64_t n_items,
-                                                        const uint8_t *__restrict__ side,
-                                                        const int32_t *__restrict__ ones, int32_t *__restrict__ perm,
-                                                        int32_t *__restrict__ tmp)
+// stable partition of one segment by side; one workgroup per node (PT threads: 1024 while nodes are large)
+template <int PT>
+__global__ __launch_bounds__(PT) void partition_kernel(const SplitTask *__restrict__ tasks, int64_t n_items,
+                                                       const uint8_t *__restrict__ side,
+                                                       const int32_t *__restrict__ ones, int32_t *__restrict__ perm,
+                                                       int32_t *__restrict__ tmp)
 {
-    __shared__ int s_w1[4];
+    __shared__ int s_w1[PT / WAVE];
     const SplitTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const int n1 = ones[blockIdx.x], n0 = t.count - n1;
     const int64_t base = (int64_t)t.tree * n_items + t.start;
     int run0 = 0, run1 = 0;   // items already placed on each side
-    for (int p0 = 0; p0 < t.count; p0 += 256) {
+    for (int p0 = 0; p0 < t.count; p0 += PT) {
         const int p = p0 + tid;
         const bool valid = p < t.count;
         const int s = valid ? side[base + p] : 0;
@@ -762,7 +763,7 @@ __global__ __launch_bounds__(256) void partition_kernel(const SplitTask *__restr
         __syncthreads();
         int ones_before = 0, ones_tile = 0, valid_before = w * WAVE;   // full waves precede a partial one
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < PT / WAVE; i++) {
             if (i < w) ones_before += s_w1[i];
             ones_tile += s_w1[i];
         }
@@ -773,13 +774,13 @@ __global__ __launch_bounds__(256) void partition_kernel(const SplitTask *__restr
             const int dst = s ? (n0 + run1 + r1) : (run0 + (rv - r1));
             tmp[base + dst] = perm[base + p];
         }
-        const int tile_valid = (t.count - p0) < 256 ? (t.count - p0) : 256;
+        const int tile_valid = (t.count - p0) < PT ? (t.count - p0) : PT;
         run1 += ones_tile;
         run0 += tile_valid - ones_tile;
         __syncthreads();
     }
     __syncthreads();
-    for (int p = tid; p < t.count; p += 256) perm[base + p] = tmp[base + p];
+    for (int p = tid; p < t.count; p += PT) perm[base + p] = tmp[base + p];
 }
 
 __global__ void iota_perm_kernel(int32_t *perm, int64_t n_items, int64_t total)
@@ -1087,8 +1088,14 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             F_TRY(hipMemcpyAsync(d_tasks.p, kept_tasks.back().data(), (size_t)S * sizeof(SplitTask), hipMemcpyHostToDevice, h->stream));
             F_TRY(hipMemcpyAsync(d_ones.p, kept_ones.back().data(), (size_t)S * 4, hipMemcpyHostToDevice, h->stream));
             ScopedTimer tm(h, MORNA_T_PARTITION, 0);
-            hipLaunchKernelGGL(partition_kernel, dim3((unsigned)S), dim3(256), 0, h->stream, d_tasks.p, N, side.p,
-                               d_ones.p, h->perm.p, tmp.p);
+            int64_t level_rows = 0;
+            for (const SplitTask &t : kept_tasks.back()) level_rows += t.count;
+            if (level_rows >= (int64_t)S * 2048)
+                hipLaunchKernelGGL(partition_kernel<1024>, dim3((unsigned)S), dim3(1024), 0, h->stream, d_tasks.p, N, side.p,
+                                   d_ones.p, h->perm.p, tmp.p);
+            else
+                hipLaunchKernelGGL(partition_kernel<256>, dim3((unsigned)S), dim3(256), 0, h->stream, d_tasks.p, N, side.p,
+                                   d_ones.p, h->perm.p, tmp.p);
         }
         F_TRY(hipGetLastError());
 
