@@ -108,7 +108,8 @@ __global__ __launch_bounds__(ACC_THREADS) void col_fill_kernel(const int32_t *__
 // ids follow first-seen order, so a line's id list is generally NOT sorted even
 // though the file's sample list is.)  Uses an LDS bitmap over the samples.
 #define FLAG_MAX_WORDS 32768   // 128 KiB of LDS: up to 2^20 samples
-__global__ __launch_bounds__(256) void line_flags_kernel(const int64_t *__restrict__ row_ptr,
+#define LF_THREADS 1024   // a line holds ~1.4 k samples: one or two per thread
+__global__ __launch_bounds__(LF_THREADS) void line_flags_kernel(const int64_t *__restrict__ row_ptr,
                                                          const int32_t *__restrict__ ids, int64_t J,
                                                          int32_t n_words, uint8_t *__restrict__ flag_out)
 {
@@ -116,14 +117,14 @@ __global__ __launch_bounds__(256) void line_flags_kernel(const int64_t *__restri
     uint32_t *bm = (uint32_t *)smem;
     __shared__ int s_dup;
     const int tid = threadIdx.x;
-    for (int i = tid; i < n_words; i += 256) bm[i] = 0u;
+    for (int i = tid; i < n_words; i += LF_THREADS) bm[i] = 0u;
     __syncthreads();
     for (int64_t j = blockIdx.x; j < J; j += gridDim.x) {
         const int64_t b = row_ptr[j], e = row_ptr[j + 1];
         if (tid == 0) s_dup = 0;
         __syncthreads();
         int dup = 0;
-        for (int64_t t = b + tid; t < e; t += 256) {
+        for (int64_t t = b + tid; t < e; t += LF_THREADS) {
             const uint32_t id = (uint32_t)ids[t];
             const uint32_t bit = 1u << (id & 31);
             dup |= (atomicOr(&bm[id >> 5], bit) & bit) != 0;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void line_flags_kernel(const int64_t *__restri
         if (dup) s_dup = 1;
         __syncthreads();
         if (tid == 0) flag_out[j] = (uint8_t)s_dup;
-        for (int64_t t = b + tid; t < e; t += 256) bm[(uint32_t)ids[t] >> 5] = 0u;   // un-set only what was set
+        for (int64_t t = b + tid; t < e; t += LF_THREADS) bm[(uint32_t)ids[t] >> 5] = 0u;   // un-set only what was set
         __syncthreads();
     }
 }
@@ -365,7 +366,7 @@ int build_features(morna_index *h, int64_t n_items)
             const int64_t n_words = (n_items + 31) / 32;
             if (n_words <= FLAG_MAX_WORDS) {
                 const int fl_blocks = (int)std::min<int64_t>(J, 256 * 4);
-                hipLaunchKernelGGL(line_flags_kernel, dim3(fl_blocks), dim3(256), (size_t)n_words * 4, h->stream,
+                hipLaunchKernelGGL(line_flags_kernel, dim3(fl_blocks), dim3(LF_THREADS), (size_t)n_words * 4, h->stream,
                                    h->s_row_ptr.p, h->s_ids.p, J, (int32_t)n_words, flags.p);
             } else {
                 // the sample bitmap does not fit LDS: take the order-preserving serial path for every line
