@@ -157,6 +157,16 @@ int morna_get_nns_by_item(morna_index *h, const int32_t *items, int64_t nq, int3
 int morna_exact_search(morna_index *h, const double *q, int64_t nq, int32_t k,
                        int32_t *ids_out, double *dist_out, int32_t *count_out);
 
+/*
+ * Row-sharded search (one handle per GPU; the reference has no such path): merge of the
+ * per-shard answers to the same queries after their all-gather.  ids / dist: [world][nq][kk], each
+ * [kk] list as get_nns_* returns it -- ascending (distance, id), empty slots id -1 last -- with ids
+ * already global.  Writes the k smallest (distance, id) pairs per query; out slots past the
+ * count are id -1 / distance +inf.  Host memory, no GPU work.
+ */
+int morna_merge_topk(const int64_t *ids, const float *dist, int32_t world, int64_t nq, int32_t kk, int32_t k,
+                     int64_t *ids_out, float *dist_out, int32_t *count_out);
+
 /* ---- persistence (stands in for AnnoyIndex.save / load)      morna.py:439, 544 */
 int morna_save(morna_index *h, const char *path);
 int morna_load(morna_index *h, const char *path);

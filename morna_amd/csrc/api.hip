@@ -596,6 +596,55 @@ int morna_timer_read(morna_index *h, int32_t which, double *ms, int64_t *launche
     return MORNA_OK;
 }
 
+int morna_merge_topk(const int64_t *ids, const float *dist, int32_t world, int64_t nq, int32_t kk, int32_t k,
+                     int64_t *ids_out, float *dist_out, int32_t *count_out)
+{
+    if (!ids || !dist || !ids_out || !dist_out || !count_out || world <= 0 || nq < 0 || kk <= 0 || k <= 0) {
+        set_error("merge_topk: invalid argument");
+        return MORNA_E_INVALID;
+    }
+    // every list is sorted: a k-way merge by (distance, id); NaN after every number, as in the kernels' keys
+    auto key = [](float d) -> uint32_t {
+        if (d == 0.f) d = 0.f;
+        uint32_t u;
+        memcpy(&u, &d, 4);
+        return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    };
+    std::vector<int32_t> head((size_t)world);
+    for (int64_t q = 0; q < nq; q++) {
+        std::fill(head.begin(), head.end(), 0);
+        int32_t n = 0;
+        for (; n < k; n++) {
+            int best = -1;
+            uint32_t bk = 0;
+            int64_t bi = 0;
+            for (int w = 0; w < world; w++) {
+                if (head[(size_t)w] >= kk) continue;
+                const size_t at = ((size_t)w * (size_t)nq + (size_t)q) * (size_t)kk + (size_t)head[(size_t)w];
+                const int64_t id = ids[at];
+                if (id < 0) continue;   // the rest of this shard's list is empty
+                const uint32_t dk = key(dist[at]);
+                if (best < 0 || dk < bk || (dk == bk && id < bi)) {
+                    best = w;
+                    bk = dk;
+                    bi = id;
+                }
+            }
+            if (best < 0) break;
+            const size_t at = ((size_t)best * (size_t)nq + (size_t)q) * (size_t)kk + (size_t)head[(size_t)best];
+            ids_out[q * k + n] = ids[at];
+            dist_out[q * k + n] = dist[at];
+            head[(size_t)best]++;
+        }
+        count_out[q] = n;
+        for (; n < k; n++) {
+            ids_out[q * k + n] = -1;
+            dist_out[q * k + n] = INFINITY;
+        }
+    }
+    return MORNA_OK;
+}
+
 int morna_synchronize(morna_index *h)
 {
     CHECK_H(h);

@@ -145,6 +145,32 @@ def test_sharded_exact_search_two_ranks_gloo():
     assert dict(ret) == {0: "ok", 1: "ok"}
 
 
+def test_native_merge_equals_numpy_merge():
+    """morna_merge_topk (C ABI, host) == the numpy (distance, id) lexsort on sorted per-shard lists with
+    ties across shards, short lists, empty shards and k larger than what exists."""
+    from morna_amd.dist import merge_topk_native
+    rng = np.random.default_rng(5)
+    for world, nq, kk, k in ((8, 300, 20, 20), (3, 50, 7, 12), (2, 9, 4, 3), (5, 40, 6, 6)):
+        d = np.round(rng.random((world, nq, kk)) * 4) / 4                 # many exact ties across shards
+        ids = np.empty((world, nq, kk), np.int64)
+        for w in range(world):
+            ids[w] = w * 1000 + rng.permuted(np.tile(np.arange(kk), (nq, 1)), axis=1)
+        n_valid = rng.integers(0, kk + 1, (world, nq))
+        n_valid[0, 0] = 0
+        for w in range(world):                                            # each list sorted by (distance, id), empties last
+            for q in range(nq):
+                order = np.lexsort((ids[w, q], d[w, q]))
+                ids[w, q], d[w, q] = ids[w, q][order], d[w, q][order]
+                ids[w, q, n_valid[w, q]:] = -1
+                d[w, q, n_valid[w, q]:] = np.inf
+        d = d.astype(np.float32)
+        a = merge_topk(ids, d, k)
+        b = merge_topk_native(ids, d, k)
+        assert a[0].tolist() == b[0].tolist()
+        assert np.array_equal(a[1].astype(np.float32), b[1])
+        assert a[2].tolist() == b[2].tolist()
+
+
 def test_merge_topk_ties_and_padding():
     ids = np.array([[[5, 9, -1]], [[2, 7, 11]]], np.int64)          # [world=2, nq=1, k=3]
     d = np.array([[[0.1, 0.5, np.inf]], [[0.1, 0.2, 0.9]]], np.float32)
