@@ -97,8 +97,14 @@ __global__ __launch_bounds__(SM_THREADS) void split_mm_kernel(
     __shared__ unsigned int s_obase;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const int wm = w >> 1, wn = w & 1;   // the wave's part of the tile: rows wm * 32 .. +31, columns wn * 64 .. +63
-    const int64_t r0 = (int64_t)blockIdx.x * SM_TILE;
-    const int c0 = (int)blockIdx.y * SM_TILE;
+    // Workgroup b runs on XCD b % 8.  An XCD takes every 8th row tile and walks that tile's hyperplane tiles
+    // back to back: the row tile (786 KB at D = 3000) is fetched from HBM once and then served by that XCD's
+    // L2; the level's hyperplanes (a few MB) stay in the Infinity Cache for everybody.
+    const int n_ct = (n_tasks + SM_TILE - 1) / SM_TILE;
+    const int64_t row_tile = (int64_t)((blockIdx.x >> 3) / n_ct) * 8 + (blockIdx.x & 7);
+    const int64_t r0 = row_tile * SM_TILE;
+    const int c0 = (int)((blockIdx.x >> 3) % n_ct) * SM_TILE;
+    if (r0 >= n_items) return;
 
     // Operand slabs go from global memory straight into LDS (global_load_lds_dwordx4: no staging registers, no
     // ds_write -- the VGPR -> LDS store path, ~80 B/clk, would take as long as the slab's MFMAs).  One wave
@@ -315,7 +321,8 @@ int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, co
     HIP_TRY(hipMemsetAsync(amb_count, 0, 16, h->stream));
     hipLaunchKernelGGL(rows_to_half_kernel, dim3((unsigned)((n_tasks + 3) / 4)), dim3(256), 0, h->stream, hp_level,
                        (int64_t)n_tasks, h->dpad, h16.p, hn.p, (float *)nullptr);
-    const dim3 grid((unsigned)((N + SM_TILE - 1) / SM_TILE), (unsigned)((n_tasks + SM_TILE - 1) / SM_TILE));
+    const unsigned n_rt = (unsigned)((N + SM_TILE - 1) / SM_TILE), n_ct = (unsigned)((n_tasks + SM_TILE - 1) / SM_TILE);
+    const dim3 grid(8u * ((n_rt + 7) / 8) * n_ct);
     HIP_TRY(hipFuncSetAttribute((const void *)split_mm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_TILE * SM_TILE * 4));
     hipLaunchKernelGGL(split_mm_kernel, grid, dim3(SM_THREADS), SM_TILE * SM_TILE * 4, h->stream, x16.p, xn.p, N, h->dpad, h16.p, hn.p, n_tasks, d_tasks,
                        row_task, row_pos, sm_eps(h->dpad), side, ones, amb_count, amb, (unsigned int)cap);
