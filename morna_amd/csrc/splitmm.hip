@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void rows_to_half_kernel(const float *__restri
 
 // ---- the contraction with the side decision fused into its epilogue --------------------------------
 #define SM_TILE 128
-#define SM_THREADS 512           // 8 waves, each a 32 x 64 part of the tile: four workgroups per CU cover each other's loads
+#define SM_THREADS 512           // 8 waves, each a 32 x 64 part of the tile; two workgroups per CU (78 KB of LDS each)
 #define SM_BK 64                 // halfs per K step
 #define SM_OPEN 1536             // open pairs a tile keeps in LDS (12 KB; ~500 expected of 16384 at the root level)
 
