@@ -9,15 +9,20 @@
 //   two_means_wave_kernel  one WAVE per split node, centroids / current row / next
 //                     row in registers: 200 sequential centroid updates, the row of
 //                     step l+1 in flight during step l (the Kiss32 stream does not
-//                     depend on data).  two_means_kernel is its LDS form (one
-//                     workgroup per node) for rows too long for the register file.
+//                     depend on data).  two_means_quad_kernel: four waves per node,
+//                     each updating a quarter of the centroid, for levels whose nodes fit
+//                     the chip at once.  two_means_kernel: the LDS form (one workgroup
+//                     per node) for rows too long for the register file.
+//   (splitmm.hip)     the sides of the whole level as one fp16 MFMA product that filters,
+//                     exact fp32 dots for the pairs it cannot decide -- the form that runs
+//                     while a tree has at most 32 split nodes.  Otherwise, and for retries:
 //   split_kernel      every row of every split node is dotted (wavefront dot product,
 //                     hyperplane resident in LDS) against its node's hyperplane, one
 //                     workgroup per 64 positions of a node; launch order sorted by row
 //                     id, one run per XCD, so the trees' re-reads hit L2.
 //   split_rw_kernel   the same work at shallow levels (<= 4 split nodes per tree) as
 //                     row windows x tree groups: a row is loaded once into registers
-//                     and used for every tree of the group.
+//                     and used for every tree of the group (runs with MORNA_SPLIT_MM=0).
 //   (host)            annoy's 3-attempt / 0.95 imbalance rule on the counts
 //   fallback_kernel   random sides for nodes still above 0.99
 //   partition_kernel  stable partition of each segment by side
