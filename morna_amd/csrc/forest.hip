@@ -976,17 +976,6 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
 #undef TMW_LAUNCH
 #undef TMQ_LAUNCH
             }
-            {
-                // launch order: chunks sorted by first row id, one contiguous run per XCD
-                if ((rc = d_info.alloc((size_t)n_chunks)) || (rc = d_sched.alloc((size_t)n_chunks))) { cleanup(); return rc; }
-                F_TRY(hipMemsetAsync(d_hist.p, 0, (size_t)n_buckets * 4, h->stream));
-                const unsigned cb = (unsigned)((n_chunks + 255) / 256);
-                hipLaunchKernelGGL(sched_bucket_kernel, dim3(cb), dim3(256), 0, h->stream, d_tasks.p, A, n_chunks, h->perm.p, N,
-                                   n_buckets, d_hist.p, d_info.p);
-                hipLaunchKernelGGL(sched_scan_kernel, dim3(1), dim3(1024), 0, h->stream, d_hist.p, n_buckets, d_cursor.p);
-                hipLaunchKernelGGL(sched_scatter_kernel, dim3(cb), dim3(256), 0, h->stream, d_tasks.p, n_chunks, d_info.p,
-                                   d_cursor.p, d_sched.p);
-            }
             // shallow level, whole level pending: row-window form (rows reused across a tree group)
             int max_per_tree = 0;
             tree_first.assign((size_t)n_trees + 1, A);
@@ -1010,6 +999,20 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             static const bool mm_on = !(getenv("MORNA_SPLIT_MM") && atoi(getenv("MORNA_SPLIT_MM")) == 0);
             const bool use_mm = mm_on && attempt == 0 && max_per_tree >= 1 && max_per_tree <= 32 &&
                                 rows * 2 >= (int64_t)n_trees * N;
+            {
+                // task of every chunk (the inverse map needs it too); for the chunk form also its launch order:
+                // chunks sorted by first row id, one contiguous run per XCD
+                if ((rc = d_info.alloc((size_t)n_chunks)) || (rc = d_sched.alloc((size_t)n_chunks))) { cleanup(); return rc; }
+                F_TRY(hipMemsetAsync(d_hist.p, 0, (size_t)n_buckets * 4, h->stream));
+                const unsigned cb = (unsigned)((n_chunks + 255) / 256);
+                hipLaunchKernelGGL(sched_bucket_kernel, dim3(cb), dim3(256), 0, h->stream, d_tasks.p, A, n_chunks, h->perm.p, N,
+                                   n_buckets, d_hist.p, d_info.p);
+                if (!use_mm && !use_rw) {
+                    hipLaunchKernelGGL(sched_scan_kernel, dim3(1), dim3(1024), 0, h->stream, d_hist.p, n_buckets, d_cursor.p);
+                    hipLaunchKernelGGL(sched_scatter_kernel, dim3(cb), dim3(256), 0, h->stream, d_tasks.p, n_chunks, d_info.p,
+                                       d_cursor.p, d_sched.p);
+                }
+            }
             if (use_mm || use_rw) {   // row -> (task, position) per tree
                 if ((rc = row_task.alloc((size_t)n_trees * N)) || (rc = row_pos.alloc((size_t)n_trees * N)) ||
                     (rc = d_tree_first.alloc((size_t)n_trees + 1))) { cleanup(); return rc; }
