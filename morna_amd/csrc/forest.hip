@@ -609,13 +609,18 @@ __global__ __launch_bounds__(SP_THREADS) void split_kernel(const float *__restri
 #define RW_SLOTS 12       // hyperplanes resident in LDS (144 KB at D = 3000): one workgroup per CU
 
 // inverse of the permutation restricted to the tasks: row -> (task index, position in segment)
-__global__ void invert_kernel(const SplitTask *__restrict__ tasks, const int2 *__restrict__ info /* task per chunk */,
-                              int32_t n_chunks, const int32_t *__restrict__ perm, int64_t n_items,
-                              int32_t *__restrict__ row_task, int32_t *__restrict__ row_pos)
+__global__ void invert_kernel(const SplitTask *__restrict__ tasks, int32_t n_tasks, int32_t n_chunks,
+                              const int32_t *__restrict__ perm, int64_t n_items, int32_t *__restrict__ row_task,
+                              int32_t *__restrict__ row_pos)
 {
     const int c = blockIdx.x;
     if (c >= n_chunks) return;
-    const int a = info[c].x;
+    int lo = 0, hi = n_tasks - 1;   // the task owning this chunk (tasks are sorted by chunk0)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tasks[mid].chunk0 <= c) lo = mid; else hi = mid - 1;
+    }
+    const int a = lo;
     const SplitTask t = tasks[a];
     const int p = (c - t.chunk0) * 64 + threadIdx.x;
     if (p < t.count) {
@@ -999,26 +1004,23 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             static const bool mm_on = !(getenv("MORNA_SPLIT_MM") && atoi(getenv("MORNA_SPLIT_MM")) == 0);
             const bool use_mm = mm_on && attempt == 0 && max_per_tree >= 1 && max_per_tree <= 32 &&
                                 rows * 2 >= (int64_t)n_trees * N;
-            {
-                // task of every chunk (the inverse map needs it too); for the chunk form also its launch order:
-                // chunks sorted by first row id, one contiguous run per XCD
+            if (!use_mm && !use_rw) {
+                // chunk form: launch order = chunks sorted by first row id, one contiguous run per XCD
                 if ((rc = d_info.alloc((size_t)n_chunks)) || (rc = d_sched.alloc((size_t)n_chunks))) { cleanup(); return rc; }
                 F_TRY(hipMemsetAsync(d_hist.p, 0, (size_t)n_buckets * 4, h->stream));
                 const unsigned cb = (unsigned)((n_chunks + 255) / 256);
                 hipLaunchKernelGGL(sched_bucket_kernel, dim3(cb), dim3(256), 0, h->stream, d_tasks.p, A, n_chunks, h->perm.p, N,
                                    n_buckets, d_hist.p, d_info.p);
-                if (!use_mm && !use_rw) {
-                    hipLaunchKernelGGL(sched_scan_kernel, dim3(1), dim3(1024), 0, h->stream, d_hist.p, n_buckets, d_cursor.p);
-                    hipLaunchKernelGGL(sched_scatter_kernel, dim3(cb), dim3(256), 0, h->stream, d_tasks.p, n_chunks, d_info.p,
-                                       d_cursor.p, d_sched.p);
-                }
+                hipLaunchKernelGGL(sched_scan_kernel, dim3(1), dim3(1024), 0, h->stream, d_hist.p, n_buckets, d_cursor.p);
+                hipLaunchKernelGGL(sched_scatter_kernel, dim3(cb), dim3(256), 0, h->stream, d_tasks.p, n_chunks, d_info.p,
+                                   d_cursor.p, d_sched.p);
             }
             if (use_mm || use_rw) {   // row -> (task, position) per tree
                 if ((rc = row_task.alloc((size_t)n_trees * N)) || (rc = row_pos.alloc((size_t)n_trees * N)) ||
                     (rc = d_tree_first.alloc((size_t)n_trees + 1))) { cleanup(); return rc; }
                 F_TRY(hipMemcpyAsync(d_tree_first.p, tree_first.data(), ((size_t)n_trees + 1) * 4, hipMemcpyHostToDevice, h->stream));
                 F_TRY(hipMemsetAsync(row_task.p, 0xFF, (size_t)n_trees * N * 4, h->stream));
-                hipLaunchKernelGGL(invert_kernel, dim3((unsigned)n_chunks), dim3(64), 0, h->stream, d_tasks.p, d_info.p, n_chunks,
+                hipLaunchKernelGGL(invert_kernel, dim3((unsigned)n_chunks), dim3(64), 0, h->stream, d_tasks.p, A, n_chunks,
                                    h->perm.p, N, row_task.p, row_pos.p);
             }
             if (use_mm) {
