@@ -941,7 +941,9 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             return chunk;
         };
 
+        int attempts_run = 0;
         for (int attempt = 0; attempt < 3 && !pending.empty(); attempt++) {
+            attempts_run++;
             const int32_t n_chunks = make_tasks(pending, attempt, tasks);
             const int32_t A = (int32_t)tasks.size();
             int64_t rows = 0;
@@ -1018,8 +1020,10 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             if (use_mm || use_rw) {   // row -> (task, position) per tree
                 if ((rc = row_task.alloc((size_t)n_trees * N)) || (rc = row_pos.alloc((size_t)n_trees * N)) ||
                     (rc = d_tree_first.alloc((size_t)n_trees + 1))) { cleanup(); return rc; }
-                F_TRY(hipMemcpyAsync(d_tree_first.p, tree_first.data(), ((size_t)n_trees + 1) * 4, hipMemcpyHostToDevice, h->stream));
-                F_TRY(hipMemsetAsync(row_task.p, 0xFF, (size_t)n_trees * N * 4, h->stream));
+                if (use_rw && !use_mm)   // only the row-window kernel reads the per-tree task ranges
+                    F_TRY(hipMemcpyAsync(d_tree_first.p, tree_first.data(), ((size_t)n_trees + 1) * 4, hipMemcpyHostToDevice, h->stream));
+                if (rows != (int64_t)n_trees * N)   // rows outside every split node must read "no task"
+                    F_TRY(hipMemsetAsync(row_task.p, 0xFF, (size_t)n_trees * N * 4, h->stream));
                 hipLaunchKernelGGL(invert_kernel, dim3((unsigned)n_chunks), dim3(64), 0, h->stream, d_tasks.p, A, n_chunks,
                                    h->perm.p, N, row_task.p, row_pos.p);
             }
@@ -1083,6 +1087,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             }
             pending.swap(still);
         }
+        const bool level_clean = attempts_run == 1 && pending.empty();   // one attempt, every node accepted
         // "If we didn't find a hyperplane, just randomize sides as a last option"
         std::vector<int32_t> fb;
         for (int32_t i : pending) {
@@ -1112,8 +1117,12 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             kept_tasks.emplace_back();
             kept_ones.push_back(final_ones);
             make_tasks(all, 0, kept_tasks.back());
-            F_TRY(hipMemcpyAsync(d_tasks.p, kept_tasks.back().data(), (size_t)S * sizeof(SplitTask), hipMemcpyHostToDevice, h->stream));
-            F_TRY(hipMemcpyAsync(d_ones.p, kept_ones.back().data(), (size_t)S * 4, hipMemcpyHostToDevice, h->stream));
+            // when every node was accepted at its first attempt, the tasks and counts of that attempt are still
+            // in d_tasks / d_ones: nothing to send
+            if (!level_clean) {
+                F_TRY(hipMemcpyAsync(d_tasks.p, kept_tasks.back().data(), (size_t)S * sizeof(SplitTask), hipMemcpyHostToDevice, h->stream));
+                F_TRY(hipMemcpyAsync(d_ones.p, kept_ones.back().data(), (size_t)S * 4, hipMemcpyHostToDevice, h->stream));
+            }
             ScopedTimer tm(h, MORNA_T_PARTITION, 0);
             int64_t level_rows = 0;
             for (const SplitTask &t : kept_tasks.back()) level_rows += t.count;
