@@ -122,7 +122,16 @@ int morna_index_create(int32_t dim, int32_t device, morna_index **out)
     }
     int rc = h->d_stat.alloc(4);
     if (rc == MORNA_OK && hipMemset(h->d_stat.p, 0, 4 * sizeof(unsigned long long)) != hipSuccess) rc = MORNA_E_HIP;
+    if (rc == MORNA_OK && (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+                           hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)) {
+        set_error("hipStreamCreate / hipEventCreate failed");
+        rc = MORNA_E_HIP;
+    }
     if (rc != MORNA_OK) {
+        if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+        if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+        if (h->stream2) (void)hipStreamDestroy(h->stream2);
         (void)hipStreamDestroy(h->stream);
         delete h;
         return rc;
@@ -141,8 +150,12 @@ int morna_index_destroy(morna_index *h)
         (void)hipEventDestroy(pe.b);
     }
     for (hipEvent_t e : h->free_ev) (void)hipEventDestroy(e);
-    hipStream_t s = h->stream;
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    hipStream_t s = h->stream, s2 = h->stream2;
     delete h;   // DevBuf destructors free HBM
+    if (s2) (void)hipStreamDestroy(s2);
     if (s) (void)hipStreamDestroy(s);
     return MORNA_OK;
 }

@@ -110,6 +110,8 @@ struct morna_index {
     int32_t n_cus = 256;               // compute units of the device (MI355X: 256)
     int32_t K = 0;       // leaf capacity D + 2
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;                 // side stream of the forest build (work that does not depend on two_means)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     // host staging of add_item() rows until build()
     std::vector<float> host_rows;  // [host_n][dim]
@@ -194,7 +196,7 @@ int hash_keys_device(morna_index *h, const uint8_t *key_bytes, const int64_t *ke
                      int32_t *hash_out, int32_t *col_out, int32_t *sign_out);
 int build_forest(morna_index *h, int32_t n_trees, uint32_t seed);
 // splitmm.hip: the split of a whole level on the matrix cores (fp16 filter, exact fp32 for what it cannot decide)
-int split_mm_prepare_rows(morna_index *h);
+int split_mm_prepare_rows(morna_index *h, hipStream_t stream);   // stream: the handle's main or side stream
 int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, const float *hp_level,
                    const int32_t *row_task, const int32_t *row_pos, uint32_t seed, uint8_t *side, int32_t *ones);
 int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int32_t *items_host, int64_t nq, int32_t k,

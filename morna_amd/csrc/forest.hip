@@ -948,8 +948,50 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             const int32_t A = (int32_t)tasks.size();
             int64_t rows = 0;
             for (const SplitTask &t : tasks) rows += t.count;
+            // shallow level, whole level pending: row-window form (rows reused across a tree group)
+            int max_per_tree = 0;
+            tree_first.assign((size_t)n_trees + 1, A);
+            for (int32_t a = A - 1; a >= 0; a--) tree_first[(size_t)tasks[(size_t)a].tree] = a;
+            for (int t = n_trees - 1; t >= 0; t--)
+                if (tree_first[(size_t)t] > tree_first[(size_t)t + 1]) tree_first[(size_t)t] = tree_first[(size_t)t + 1];
+            for (int t = 0; t < n_trees; t++)
+                max_per_tree = std::max(max_per_tree, tree_first[(size_t)t + 1] - tree_first[(size_t)t]);
+            const int nv = (dpad / 4 + WAVE - 1) / WAVE;
+            // measured on MI355X (C3, 1e7 rows per level): 2.4 / 2.8 / 3.8 ms with 1 / 2 / 4 nodes per tree
+            // against 4.7 ms for the chunk form, so it is used while a tree has at most 4 split nodes
+            // (MORNA_SPLIT_RW=0 turns it off, =2 restricts it to 2 nodes per tree)
+            static const int rw_max = getenv("MORNA_SPLIT_RW") ? atoi(getenv("MORNA_SPLIT_RW")) : 4;
+            const bool nv_ok = nv == 1 || nv == 2 || nv == 3 || nv == 4 || nv == 6 || nv == 8 || nv == 12;
+            const bool use_rw = attempt == 0 && max_per_tree >= 1 && max_per_tree <= std::min(rw_max, RW_SLOTS / 2) &&
+                                nv_ok && rows * 2 >= (int64_t)n_trees * N;
+            // While a tree has few split nodes and most rows still sit in split nodes, the whole level is one
+            // contraction on the matrix cores (splitmm.hip): its cost grows with the nodes per tree (every row
+            // meets every hyperplane), the chunk form's does not -- they meet near 64 nodes per tree.
+            // MORNA_SPLIT_MM=0 turns it off (row-window / chunk forms as before).
+            static const bool mm_on = !(getenv("MORNA_SPLIT_MM") && atoi(getenv("MORNA_SPLIT_MM")) == 0);
+            const bool use_mm = mm_on && attempt == 0 && max_per_tree >= 1 && max_per_tree <= 32 &&
+                                rows * 2 >= (int64_t)n_trees * N;
             F_TRY(hipMemcpyAsync(d_tasks.p, tasks.data(), (size_t)A * sizeof(SplitTask), hipMemcpyHostToDevice, h->stream));
             F_TRY(hipMemsetAsync(d_ones.p, 0, (size_t)A * 4, h->stream));
+            bool side_work = false;
+            if (use_mm || use_rw) {
+                // row -> (task, position) per tree, and, the first time, the fp16 image of the rows: both depend only on
+                // the task list and the previous partition, not on this level's two_means, so they run on the side
+                // stream while two_means (a latency chain on few CUs at the shallow levels) has the main one
+                if ((rc = row_task.alloc((size_t)n_trees * N)) || (rc = row_pos.alloc((size_t)n_trees * N)) ||
+                    (rc = d_tree_first.alloc((size_t)n_trees + 1))) { cleanup(); return rc; }
+                F_TRY(hipEventRecord(h->ev_fork, h->stream));
+                F_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+                if (use_rw && !use_mm)   // only the row-window kernel reads the per-tree task ranges
+                    F_TRY(hipMemcpyAsync(d_tree_first.p, tree_first.data(), ((size_t)n_trees + 1) * 4, hipMemcpyHostToDevice, h->stream2));
+                if (rows != (int64_t)n_trees * N)   // rows outside every split node must read "no task"
+                    F_TRY(hipMemsetAsync(row_task.p, 0xFF, (size_t)n_trees * N * 4, h->stream2));
+                hipLaunchKernelGGL(invert_kernel, dim3((unsigned)n_chunks), dim3(64), 0, h->stream2, d_tasks.p, A, n_chunks,
+                                   h->perm.p, N, row_task.p, row_pos.p);
+                if (use_mm && (rc = split_mm_prepare_rows(h, h->stream2))) { cleanup(); return rc; }   // once per set of rows
+                F_TRY(hipEventRecord(h->ev_join, h->stream2));
+                side_work = true;
+            }
             {
                 ScopedTimer tm(h, MORNA_T_TWO_MEANS, 4 * (int64_t)D * (TM_ITERS + 2) * A);
                 const int nvq = (dpad / 4 + WAVE - 1) / WAVE;   // float4 per lane per row
@@ -983,29 +1025,6 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
 #undef TMW_LAUNCH
 #undef TMQ_LAUNCH
             }
-            // shallow level, whole level pending: row-window form (rows reused across a tree group)
-            int max_per_tree = 0;
-            tree_first.assign((size_t)n_trees + 1, A);
-            for (int32_t a = A - 1; a >= 0; a--) tree_first[(size_t)tasks[(size_t)a].tree] = a;
-            for (int t = n_trees - 1; t >= 0; t--)
-                if (tree_first[(size_t)t] > tree_first[(size_t)t + 1]) tree_first[(size_t)t] = tree_first[(size_t)t + 1];
-            for (int t = 0; t < n_trees; t++)
-                max_per_tree = std::max(max_per_tree, tree_first[(size_t)t + 1] - tree_first[(size_t)t]);
-            const int nv = (dpad / 4 + WAVE - 1) / WAVE;
-            // measured on MI355X (C3, 1e7 rows per level): 2.4 / 2.8 / 3.8 ms with 1 / 2 / 4 nodes per tree
-            // against 4.7 ms for the chunk form, so it is used while a tree has at most 4 split nodes
-            // (MORNA_SPLIT_RW=0 turns it off, =2 restricts it to 2 nodes per tree)
-            static const int rw_max = getenv("MORNA_SPLIT_RW") ? atoi(getenv("MORNA_SPLIT_RW")) : 4;
-            const bool nv_ok = nv == 1 || nv == 2 || nv == 3 || nv == 4 || nv == 6 || nv == 8 || nv == 12;
-            const bool use_rw = attempt == 0 && max_per_tree >= 1 && max_per_tree <= std::min(rw_max, RW_SLOTS / 2) &&
-                                nv_ok && rows * 2 >= (int64_t)n_trees * N;
-            // While a tree has few split nodes and most rows still sit in split nodes, the whole level is one
-            // contraction on the matrix cores (splitmm.hip): its cost grows with the nodes per tree (every row
-            // meets every hyperplane), the chunk form's does not -- they meet near 64 nodes per tree.
-            // MORNA_SPLIT_MM=0 turns it off (row-window / chunk forms as before).
-            static const bool mm_on = !(getenv("MORNA_SPLIT_MM") && atoi(getenv("MORNA_SPLIT_MM")) == 0);
-            const bool use_mm = mm_on && attempt == 0 && max_per_tree >= 1 && max_per_tree <= 32 &&
-                                rows * 2 >= (int64_t)n_trees * N;
             if (!use_mm && !use_rw) {
                 // chunk form: launch order = chunks sorted by first row id, one contiguous run per XCD
                 if ((rc = d_info.alloc((size_t)n_chunks)) || (rc = d_sched.alloc((size_t)n_chunks))) { cleanup(); return rc; }
@@ -1017,19 +1036,9 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 hipLaunchKernelGGL(sched_scatter_kernel, dim3(cb), dim3(256), 0, h->stream, d_tasks.p, n_chunks, d_info.p,
                                    d_cursor.p, d_sched.p);
             }
-            if (use_mm || use_rw) {   // row -> (task, position) per tree
-                if ((rc = row_task.alloc((size_t)n_trees * N)) || (rc = row_pos.alloc((size_t)n_trees * N)) ||
-                    (rc = d_tree_first.alloc((size_t)n_trees + 1))) { cleanup(); return rc; }
-                if (use_rw && !use_mm)   // only the row-window kernel reads the per-tree task ranges
-                    F_TRY(hipMemcpyAsync(d_tree_first.p, tree_first.data(), ((size_t)n_trees + 1) * 4, hipMemcpyHostToDevice, h->stream));
-                if (rows != (int64_t)n_trees * N)   // rows outside every split node must read "no task"
-                    F_TRY(hipMemsetAsync(row_task.p, 0xFF, (size_t)n_trees * N * 4, h->stream));
-                hipLaunchKernelGGL(invert_kernel, dim3((unsigned)n_chunks), dim3(64), 0, h->stream, d_tasks.p, A, n_chunks,
-                                   h->perm.p, N, row_task.p, row_pos.p);
-            }
+            if (side_work) F_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
             if (use_mm) {
                 ScopedTimer tm(h, MORNA_T_SPLIT, 4 * (int64_t)D * (rows + A));
-                if ((rc = split_mm_prepare_rows(h))) { cleanup(); return rc; }   // once per set of rows
                 if ((rc = split_mm_level(h, d_tasks.p, A, hp_level, row_task.p, row_pos.p, seed, side.p, d_ones.p))) {
                     cleanup();
                     return rc;

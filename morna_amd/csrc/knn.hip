@@ -313,7 +313,7 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
     // query has many more candidates than results
     static const bool filter_on = !(getenv("MORNA_QUERY_FILTER") && atoi(getenv("MORNA_QUERY_FILTER")) == 0);
     const bool use_filter = filter_on && cap > 4 * (int64_t)k;
-    if (use_filter) MORNA_TRY(split_mm_prepare_rows(h));
+    if (use_filter) MORNA_TRY(split_mm_prepare_rows(h, h->stream));
     DevBuf<int32_t> d_items;
     if (items_host) MORNA_TRY(d_items.alloc((size_t)batch));
 

@@ -287,14 +287,14 @@ __global__ __launch_bounds__(256) void split_amb_kernel(const float *__restrict_
 
 // scratch slots 19..23 of the handle: fp16 rows, their norms, fp16 hyperplanes of the level, their norms,
 // the open-pair list (first 16 bytes: its counter)
-int split_mm_prepare_rows(morna_index *h)
+int split_mm_prepare_rows(morna_index *h, hipStream_t stream)
 {
     if (h->half_valid) return MORNA_OK;
     ScratchRef<_Float16> x16(h->scratch[19]);
     ScratchRef<float> xn(h->scratch[20]);   // [0, N): norms; [N, 2N): 2^-e per row (the query filter unscales with it)
     MORNA_TRY(x16.alloc((size_t)h->n_items * h->dpad));
     MORNA_TRY(xn.alloc((size_t)h->n_items * 2));
-    hipLaunchKernelGGL(rows_to_half_kernel, dim3((unsigned)((h->n_items + 3) / 4)), dim3(256), 0, h->stream, h->X.p,
+    hipLaunchKernelGGL(rows_to_half_kernel, dim3((unsigned)((h->n_items + 3) / 4)), dim3(256), 0, stream, h->X.p,
                        h->n_items, h->dpad, x16.p, xn.p, xn.p + h->n_items);
     HIP_TRY(hipGetLastError());
     h->half_valid = true;
