@@ -363,18 +363,24 @@ int build_features(morna_index *h, int64_t n_items)
             hipLaunchKernelGGL(hash_keys_kernel, dim3((unsigned)((J + 255) / 256)), dim3(256), 0, h->stream,
                                h->s_keys.p, h->s_key_off.p, J, D, h->s_idf.p, col.p, sidf.p, (int32_t *)nullptr,
                                (int32_t *)nullptr, col_count.p);
+            // the duplicate flags of the lines depend only on the staged ids: side stream, beside the hashing and
+            // the bucketing of the lines by column
+            HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
+            HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
             const int64_t n_words = (n_items + 31) / 32;
             if (n_words <= FLAG_MAX_WORDS) {
                 const int fl_blocks = (int)std::min<int64_t>(J, 256 * 4);
-                hipLaunchKernelGGL(line_flags_kernel, dim3(fl_blocks), dim3(LF_THREADS), (size_t)n_words * 4, h->stream,
+                hipLaunchKernelGGL(line_flags_kernel, dim3(fl_blocks), dim3(LF_THREADS), (size_t)n_words * 4, h->stream2,
                                    h->s_row_ptr.p, h->s_ids.p, J, (int32_t)n_words, flags.p);
             } else {
                 // the sample bitmap does not fit LDS: take the order-preserving serial path for every line
-                HIP_TRY(hipMemsetAsync(flags.p, 1, (size_t)J, h->stream));
+                HIP_TRY(hipMemsetAsync(flags.p, 1, (size_t)J, h->stream2));
             }
+            HIP_TRY(hipEventRecord(h->ev_join, h->stream2));
         }
         hipLaunchKernelGGL(col_scan_kernel, dim3(1), dim3(1024), 0, h->stream, col_count.p, D, col_off.p);
         hipLaunchKernelGGL(col_fill_kernel, dim3(D), dim3(ACC_THREADS), 0, h->stream, col.p, J, col_off.p, col_lines.p);
+        if (J > 0) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
         const unsigned tiles = (unsigned)((n_items + ACC_TILE - 1) / ACC_TILE);
         // workgroup b runs on XCD b % 8: the sample tiles of one column are dealt to ONE XCD, back to back, so the
         // column's lines come from HBM once and from that XCD's L2 for the other tiles
