@@ -84,6 +84,15 @@ struct SplitTask {
     int32_t pad;
 };
 
+// What two_means needs to know of a row besides its elements, made once per set of rows (row_norms_kernel) and
+// fetched with one 16-byte load per step: the operations are the ones the step would otherwise perform itself.
+struct alignas(16) RowInfo {
+    float norm2;    // canonical dot(x, x)
+    float norm;     // sqrtf(norm2); SIGN BIT SET when some x_i / norm may be a non-zero subnormal (centroid_step4)
+    double rnorm;   // RN64(1 / (double)norm)
+};
+static_assert(sizeof(RowInfo) == 16, "RowInfo is one dwordx4");
+
 // A node of the forest as the host driver tracks it (perm segment of one tree).
 struct Seg {
     int32_t tree, level, start, count, node;
@@ -122,6 +131,7 @@ struct morna_index {
     int64_t n_items = 0;
     morna::DevBuf<float> X;      // [n_items][dpad], pad columns zero
     morna::DevBuf<float> norm2;  // [n_items] canonical dot(x, x)
+    morna::DevBuf<morna::RowInfo> rowinfo;   // [n_items] norm2 again with what two_means derives from it
     bool norms_valid = false;
     bool half_valid = false;     // scratch[19] / [20] hold the fp16 image of X, its norms and scales (splitmm.hip)
 

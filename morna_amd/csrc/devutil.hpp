@@ -121,17 +121,53 @@ __device__ inline float ang_dist(float pp, float qq, float pq)
     return 2.0f;
 }
 
+// A wave-uniform look-up issued through the VECTOR memory path.  Scalar loads return out of order, so the first
+// s_waitcnt lgkmcnt(0) after one -- every LDS read, every constant look-up -- waits for it in full; vector loads
+// are counted in order and can stay in flight for a whole two_means step (its prefetches are a step or more ahead).
+template <typename T>
+__device__ inline T vgather(const T *base, uint32_t i)
+{
+    asm volatile("" : "+v"(i));   // the compiler no longer knows that all lanes hold the same index
+    return base[i];
+}
+
 // One step of annoy's two_means centroid update for four elements, (c * n + x / |x|) / (n + 1), every
 // operation rounded to fp32 as the scalar code rounds it.  The two quotients are taken through fp64
 // reciprocals, r1 = RN64(1 / |x|), r2 = RN64(1 / (n + 1)): a quotient a / b of two floats is never exactly
 // on, nor within 2^-49 (relative) of, a rounding boundary of float (a - b * mid is a non-zero multiple of
 // ulp(b) * ulp(mid) for every midpoint mid), and RN64(a * RN64(1 / b)) is within 2^-52 of a / b, so its
-// nearest float IS RN32(a / b).  That argument needs a normal float result: the rare results below the
-// normal range are recomputed with real divisions (the branch is wave-uniform).  All 64 lanes must call.
-__device__ inline float4 centroid_step4(const float4 c, const float4 x, float f0, float f1, float norm, double r1,
-                                        double r2)
+// nearest float IS RN32(a / b).  Below the normal range the spacing of floats is fixed and a quotient CAN be an
+// exact tie; a / b then lies between two subnormals (or a subnormal and FLT_MIN or 0) and ties-to-even picks
+// the even one, while the fp64 route returns one of the two: when it is wrong it has returned the odd one, a
+// non-zero subnormal.  (Away from a tie the distance argument holds a fortiori.)  So a result that is not a
+// non-zero subnormal is right, and the rare steps with one are recomputed with real divisions (the branch is
+// wave-uniform; kernels run with fp32 denormals on).  Whether x / |x| can be subnormal at all is a property of
+// the row, found once when its norm is taken (RowInfo): such rows take the real divisions for the whole step
+// (`force`), and only the second quotient is looked at here.
+// All 64 lanes must call.
+// the step as written: two real divisions per element
+__device__ inline float4 centroid_div4(const float4 c, const float4 x, float f0, float f1, float norm)
 {
-    const float tiny = 1.17549435e-38f;   // FLT_MIN
+    float4 o;
+    o.x = (c.x * f0 + x.x / norm) / f1;
+    o.y = (c.y * f0 + x.y / norm) / f1;
+    o.z = (c.z * f0 + x.z / norm) / f1;
+    o.w = (c.w * f0 + x.w / norm) / f1;
+    return o;
+}
+// lanes whose v is a non-zero subnormal: one v_cmp_class_f32 straight into a lane mask (the bool route through
+// __builtin_amdgcn_classf + ballot costs two more VALU operations per value)
+__device__ inline unsigned long long subnormal_lanes(float v)
+{
+    unsigned long long m;
+    asm("v_cmp_class_f32_e64 %0, %1, %2" : "=s"(m) : "v"(v), "s"(0x90));   // 0x90: -denormal | +denormal
+    return m;
+}
+// `force`: all ones for a row whose RowInfo says x / |x| may have a subnormal element (real divisions for the
+// whole step), else 0 -- one more scalar OR, and a single definition of the new centroid for the compiler
+__device__ inline float4 centroid_step4(const float4 c, const float4 x, float f0, float f1, float norm, double r1,
+                                        double r2, unsigned long long force)
+{
     const float nx = (float)((double)x.x * r1), ny = (float)((double)x.y * r1);
     const float nz = (float)((double)x.z * r1), nw = (float)((double)x.w * r1);
     const float tx = c.x * f0 + nx, ty = c.y * f0 + ny, tz = c.z * f0 + nz, tw = c.w * f0 + nw;
@@ -140,16 +176,8 @@ __device__ inline float4 centroid_step4(const float4 c, const float4 x, float f0
     o.y = (float)((double)ty * r2);
     o.z = (float)((double)tz * r2);
     o.w = (float)((double)tw * r2);
-    const bool sus = (fabsf(nx) < tiny && x.x != 0.f) || (fabsf(ny) < tiny && x.y != 0.f) ||
-                     (fabsf(nz) < tiny && x.z != 0.f) || (fabsf(nw) < tiny && x.w != 0.f) ||
-                     (fabsf(o.x) < tiny && tx != 0.f) || (fabsf(o.y) < tiny && ty != 0.f) ||
-                     (fabsf(o.z) < tiny && tz != 0.f) || (fabsf(o.w) < tiny && tw != 0.f);
-    if (__any(sus)) {
-        o.x = (c.x * f0 + x.x / norm) / f1;
-        o.y = (c.y * f0 + x.y / norm) / f1;
-        o.z = (c.z * f0 + x.z / norm) / f1;
-        o.w = (c.w * f0 + x.w / norm) / f1;
-    }
+    const unsigned long long sus = ((subnormal_lanes(o.x) | subnormal_lanes(o.y)) | (subnormal_lanes(o.z) | subnormal_lanes(o.w))) | force;
+    if (__builtin_expect(sus != 0, 0)) o = centroid_div4(c, x, f0, f1, norm);   // wave-uniform, and laid out off the hot path
     return o;
 }
 

@@ -254,15 +254,56 @@ __global__ __launch_bounds__(256) void transpose_convert_kernel(const double *__
 // ------------------------------------------------------------------ row norms
 
 __global__ __launch_bounds__(256) void row_norms_kernel(const float *__restrict__ X, int64_t n_items,
-                                                        int32_t dpad, float *__restrict__ norm2)
+                                                        int32_t dpad, float *__restrict__ norm2,
+                                                        RowInfo *__restrict__ info)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) / WAVE;
+    const int nvec = dpad / 4;
     for (int64_t r = wave; r < n_items; r += nwaves) {
         const float4 *x = (const float4 *)(X + r * dpad);
-        float d = wave_dot(x, x, dpad / 4, lane);
-        if (lane == 0) norm2[r] = d;
+        // wave_dot(x, x) with the row read once, and the smallest non-zero |x_i| taken on the way
+        Acc4 s = acc4_zero();
+        float mn = INFINITY;
+        auto low = [&](const float4 &v) {
+            mn = fminf(mn, v.x != 0.f ? fabsf(v.x) : INFINITY);
+            mn = fminf(mn, v.y != 0.f ? fabsf(v.y) : INFINITY);
+            mn = fminf(mn, v.z != 0.f ? fabsf(v.z) : INFINITY);
+            mn = fminf(mn, v.w != 0.f ? fabsf(v.w) : INFINITY);
+        };
+        int i = lane;
+        for (; i + 3 * WAVE < nvec; i += 4 * WAVE) {
+            const float4 v0 = x[i], v1 = x[i + WAVE], v2 = x[i + 2 * WAVE], v3 = x[i + 3 * WAVE];
+            fma4(s, v0, v0);
+            fma4(s, v1, v1);
+            fma4(s, v2, v2);
+            fma4(s, v3, v3);
+            low(v0);
+            low(v1);
+            low(v2);
+            low(v3);
+        }
+        for (; i < nvec; i += WAVE) {
+            const float4 v = x[i];
+            fma4(s, v, v);
+            low(v);
+        }
+        const float d = acc4_finish(s);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off, WAVE));
+        if (lane == 0) {
+            norm2[r] = d;
+            // what every two_means step on this row would compute from norm2 (forest.hip), computed here once
+            const float norm = sqrtf(d);
+            // x_i / norm rounds to a subnormal only if |x_i| < norm * 2^-126 * (1 + 2^-24); a factor 2 of slack
+            const bool sub = (double)mn < (double)norm * 0x1p-125;
+            RowInfo ri;
+            ri.norm2 = d;
+            ri.norm = sub ? -norm : norm;
+            ri.rnorm = 1.0 / (double)norm;
+            info[r] = ri;
+        }
     }
 }
 
@@ -271,11 +312,12 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float *__restrict_
 int compute_norms(morna_index *h)
 {
     MORNA_TRY(h->norm2.alloc((size_t)h->n_items));
+    MORNA_TRY(h->rowinfo.alloc((size_t)h->n_items));
     if (h->n_items > 0) {
         int64_t waves = h->n_items;
         int blocks = (int)std::min<int64_t>((waves + 3) / 4, 256 * 16);
         hipLaunchKernelGGL(row_norms_kernel, dim3(blocks), dim3(256), 0, h->stream, h->X.p, h->n_items,
-                           h->dpad, h->norm2.p);
+                           h->dpad, h->norm2.p, h->rowinfo.p);
         HIP_TRY(hipGetLastError());
     }
     h->norms_valid = true;

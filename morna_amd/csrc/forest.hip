@@ -217,15 +217,36 @@ __device__ inline void reg_normalize(float4 (&v)[NV])
     }
 }
 
+// RN64(1 / n) for the counts a centroid can reach in TM_ITERS steps (1 + 200, then + 1): the same correctly
+// rounded quotient the step would compute, folded by the compiler and read through the scalar cache.
+struct RecipTable {
+    double v[TM_ITERS + 8];
+    constexpr RecipTable() : v()
+    {
+        for (int n = 1; n < TM_ITERS + 8; n++) v[n] = 1.0 / (double)n;
+    }
+};
+__constant__ RecipTable k_recip = RecipTable();
+__device__ inline double tm_recip(int n) { return k_recip.v[__builtin_amdgcn_readfirstlane(n)]; }   // n is wave-uniform
+
+// One wave per node: both centroids and the current row in registers (3 x NV float4 per lane).  The row of the
+// NEXT step is fetched by LDS-DMA (global_load_lds, no destination registers) at the top of a step and read into
+// the row registers when the step's update is done: a register double buffer instead (NV = 12: 48 more VGPRs
+// and 24 v_mov per step) does not fit two waves per SIMD without spilling, and a spill inside this loop waits
+// for the whole prefetch (vmcnt is counted in order).
 template <int NV>
-__global__ __launch_bounds__(256) void two_means_wave_kernel(const float *__restrict__ X, const float *__restrict__ norm2,
+__global__ __launch_bounds__(256, 2) void two_means_wave_kernel(const float *__restrict__ X, const RowInfo *__restrict__ rowinfo,
                                                              int64_t n_items, int32_t dpad,
                                                              const int32_t *__restrict__ perm,
                                                              const SplitTask *__restrict__ tasks, int32_t n_tasks,
                                                              uint32_t seed, float *__restrict__ hp)
 {
+    __shared__ float4 xnext[256 / WAVE][NV * WAVE];   // per wave: the row of the coming step
     const int lane = threadIdx.x & (WAVE - 1);
-    const int ti = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
+    // the wave number as a scalar: the task, the node's Kiss32 stream and the row base addresses are then
+    // wave-uniform to the compiler (scalar registers)
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+    const int ti = blockIdx.x * (256 / WAVE) + wv;
     if (ti >= n_tasks) return;   // no barrier below: waves are independent
     const SplitTask t = tasks[ti];
     const int nvec = dpad / 4;
@@ -235,54 +256,79 @@ __global__ __launch_bounds__(256) void two_means_wave_kernel(const float *__rest
     uint32_t i = rng.index((uint32_t)t.count);
     uint32_t j = rng.index((uint32_t)t.count - 1u);
     j += (j >= i);
-    float4 p[NV], q[NV], x[NV], xn[NV];
+    float4 p[NV], q[NV], x[NV];
     reg_load_row<NV>(X + (int64_t)items[i] * dpad, nvec, lane, p);
     reg_load_row<NV>(X + (int64_t)items[j] * dpad, nvec, lane, q);
     reg_normalize<NV>(p);
     reg_normalize<NV>(q);
     float pp = reg_dot<NV>(p, p), qq = reg_dot<NV>(q, q);
     uint32_t k = rng.index((uint32_t)t.count);
-    int32_t it = items[k];
+    const int32_t it = items[k];
     reg_load_row<NV>(X + (int64_t)it * dpad, nvec, lane, x);
-    // The Kiss32 stream does not depend on data: the INDEX of row l+2 and the norm of row l+1 are requested a step
+    // The Kiss32 stream does not depend on data: the INDEX of row l+2 and the RowInfo of row l+1 are requested a step
     // before row l+1 itself, so that row's load never waits for its index (two dependent HBM round trips per step
     // otherwise bound the deep levels).  Draws past step 199 are never used: the stream is the node's own.
-    int32_t it_n1 = items[rng.index((uint32_t)t.count)];
-    float nk2 = norm2[it];
+    // These look-ups go through the vector memory path (vgather) and come back to scalar registers when used.
+    int32_t it_n1 = vgather(items, rng.index((uint32_t)t.count));
+    RowInfo riv = vgather(rowinfo, (uint32_t)it);   // in flight: RowInfo of the row of the coming step
+    float4 *xl = xnext[wv];
 
     int ic = 1, jc = 1;
+    double r2p = tm_recip(2), r2q = tm_recip(2);   // 1 / (ic + 1), 1 / (jc + 1), fetched when the count changes
     for (int l = 0; l < TM_ITERS; l++) {
-        const bool more = l + 1 < TM_ITERS;
-        const int32_t it_next = it_n1;
-        if (more) reg_load_row<NV>(X + (int64_t)it_next * dpad, nvec, lane, xn);   // row l+1 while row l is used
-        it_n1 = items[rng.index((uint32_t)t.count)];                                // index of row l+2
-        const float nk2_next = norm2[it_next];
+        // this step's row: what was requested a step ago, now wave-uniform values in scalar registers
+        const float nk2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(riv.norm2)));
+        const int norm_bits = __builtin_amdgcn_readfirstlane(__float_as_int(riv.norm));
+        const long long r1_bits = ((long long)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(riv.rnorm) >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)__double_as_longlong(riv.rnorm));
+        const int32_t it_next = __builtin_amdgcn_readfirstlane(it_n1);
+        {
+            // row l+1 -> LDS while row l is used; the reads of the previous row out of this buffer have returned.
+            // (After the last step this fetches a row nobody uses: the stream has more draws and every index is valid.)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const float4 *src = (const float4 *)(X + (int64_t)it_next * dpad) + lane;
+            // the instruction's immediate offset (< 4 KiB) moves both addresses: one base per four 1-KiB pieces
+#define TM_GLDS(KK)                                                                                                       \
+    if constexpr ((KK) < NV)                                                                                              \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + ((KK) & ~3) * WAVE),      \
+                                         (__attribute__((address_space(3))) void *)(xl + ((KK) & ~3) * WAVE), 16,         \
+                                         ((KK) & 3) * 1024, 0)
+            TM_GLDS(0); TM_GLDS(1); TM_GLDS(2); TM_GLDS(3); TM_GLDS(4); TM_GLDS(5);
+            TM_GLDS(6); TM_GLDS(7); TM_GLDS(8); TM_GLDS(9); TM_GLDS(10); TM_GLDS(11);
+#undef TM_GLDS
+            static_assert(NV <= 12, "TM_GLDS list");
+        }
+        it_n1 = vgather(items, rng.index((uint32_t)t.count));   // index of row l+2
+        riv = vgather(rowinfo, (uint32_t)it_next);
         const float di = (float)ic * ang_dist(pp, nk2, reg_dot<NV>(p, x));
         const float dj = (float)jc * ang_dist(qq, nk2, reg_dot<NV>(q, x));
-        const float norm = sqrtf(nk2);
+        const float norm = __int_as_float(norm_bits & 0x7fffffff);   // sqrtf(nk2)
+        const unsigned long long force = norm_bits < 0 ? ~0ull : 0ull;   // x / norm may be subnormal somewhere in this row
+        const double r1 = __longlong_as_double(r1_bits);
         if (norm > 0.f) {
             if (di < dj) {
                 const float f0 = (float)ic, f1 = (float)(ic + 1);
-                const double r1 = 1.0 / (double)norm, r2 = 1.0 / (double)f1;
 #pragma unroll
-                for (int kk = 0; kk < NV; kk++) p[kk] = centroid_step4(p[kk], x[kk], f0, f1, norm, r1, r2);
+                for (int kk = 0; kk < NV; kk++) p[kk] = centroid_step4(p[kk], x[kk], f0, f1, norm, r1, r2p, force);
                 pp = reg_dot<NV>(p, p);
                 ic++;
-            } else if (dj < di) {
+                r2p = tm_recip(ic + 1);
+            }
+            // not `else if`: as two independent branches each centroid is updated in place; chained, the compiler
+            // writes the new p to a second set of registers and copies p there on every step that leaves it alone
+            if (dj < di) {
                 const float f0 = (float)jc, f1 = (float)(jc + 1);
-                const double r1 = 1.0 / (double)norm, r2 = 1.0 / (double)f1;
 #pragma unroll
-                for (int kk = 0; kk < NV; kk++) q[kk] = centroid_step4(q[kk], x[kk], f0, f1, norm, r1, r2);
+                for (int kk = 0; kk < NV; kk++) q[kk] = centroid_step4(q[kk], x[kk], f0, f1, norm, r1, r2q, force);
                 qq = reg_dot<NV>(q, q);
                 jc++;
+                r2q = tm_recip(jc + 1);
             }
         }
-        if (more) {
+        // the row registers are free: row l+1 has had the whole step to land in LDS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int kk = 0; kk < NV; kk++) x[kk] = xn[kk];
-            it = it_next;
-            nk2 = nk2_next;
-        }
+        for (int kk = 0; kk < NV; kk++) x[kk] = xl[kk * WAVE + lane];
     }
     // create_split: n = normalize(p - q)
 #pragma unroll
@@ -322,7 +368,7 @@ __device__ inline float4 quad_pick(const float4 (&c)[NV], int w, int s)
 // does both dots, both distances and the full read-back of the centroid, and twelve waves meet at the barrier:
 // 0.61 ms instead of 0.44 ms at the root level of C3.
 template <int NV, int W>
-__global__ __launch_bounds__(64 * W) void two_means_quad_kernel(const float *__restrict__ X, const float *__restrict__ norm2,
+__global__ __launch_bounds__(64 * W) void two_means_quad_kernel(const float *__restrict__ X, const RowInfo *__restrict__ rowinfo,
                                                              int64_t n_items, int32_t dpad,
                                                              const int32_t *__restrict__ perm,
                                                              const SplitTask *__restrict__ tasks, uint32_t seed,
@@ -375,10 +421,11 @@ __global__ __launch_bounds__(64 * W) void two_means_quad_kernel(const float *__r
             xs1[s] = x1[s * WAVE];
         }
     }
-    float nk2 = norm2[it0], nk2_1 = norm2[it1];
+    RowInfo ri = rowinfo[it0], ri_1 = rowinfo[it1];
     __syncthreads();
 
     int ic = 1, jc = 1;
+    double r2p = tm_recip(2), r2q = tm_recip(2);   // 1 / (ic + 1), 1 / (jc + 1), fetched when the count changes
     for (int l = 0; l < TM_ITERS; l++) {
         const int par = l & 1;
         const float4 *xrow = rbuf[par];
@@ -387,13 +434,14 @@ __global__ __launch_bounds__(64 * W) void two_means_quad_kernel(const float *__r
         // row l+3 and the norm of row l+2 are requested as well
 #pragma unroll
         for (int s = 0; s < NS; s++) rbuf[par ^ 1][soff + s * WAVE] = xs1[s];
-        const int32_t it3 = items[rng.index((uint32_t)t.count)];
+        const int32_t it3 = vgather(items, rng.index((uint32_t)t.count));
         {
             const float4 *x2 = (const float4 *)(X + (int64_t)it2 * dpad) + soff;
 #pragma unroll
             for (int s = 0; s < NS; s++) xs1[s] = x2[s * WAVE];
         }
-        const float nk2_2 = norm2[it2];
+        const RowInfo ri_2 = vgather(rowinfo, (uint32_t)it2);
+        const float nk2 = ri.norm2;
         // both dots against the row in LDS, reduced together (p.x in lane 0, q.x in lane 32)
         Acc4 a = acc4_zero(), b = acc4_zero();
 #pragma unroll
@@ -408,18 +456,21 @@ __global__ __launch_bounds__(64 * W) void two_means_quad_kernel(const float *__r
         const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u), 32));
         const float di = (float)ic * ang_dist(pp, nk2, px);
         const float dj = (float)jc * ang_dist(qq, nk2, qx);
-        const float norm = sqrtf(nk2);
+        const float norm = fabsf(ri.norm);   // sqrtf(nk2)
+        // x / norm may be subnormal somewhere in this row: real divisions for the step
+        const unsigned long long force = __builtin_amdgcn_readfirstlane(__float_as_int(ri.norm)) < 0 ? ~0ull : 0ull;
         int upd = 0;   // the same in all four waves
         if (norm > 0.f) upd = di < dj ? 1 : (dj < di ? 2 : 0);
         if (upd) {
             const float f0 = upd == 1 ? (float)ic : (float)jc, f1 = f0 + 1.f;   // counts are small integers: exact
-            const double r1 = 1.0 / (double)norm, r2 = 1.0 / (double)f1;
+            const double r1 = ri.rnorm, r2 = upd == 1 ? r2p : r2q;
 #pragma unroll
             for (int s = 0; s < NS; s++) {
                 float4 c;
                 EW4(c, upd == 1 ? ps[s].x : qs[s].x, upd == 1 ? ps[s].y : qs[s].y, upd == 1 ? ps[s].z : qs[s].z,
                     upd == 1 ? ps[s].w : qs[s].w);
-                cbuf[par][soff + s * WAVE] = centroid_step4(c, xrow[soff + s * WAVE], f0, f1, norm, r1, r2);
+                const float4 xv = xrow[soff + s * WAVE];
+                cbuf[par][soff + s * WAVE] = centroid_step4(c, xv, f0, f1, norm, r1, r2, force);
             }
         }
         __syncthreads();
@@ -430,6 +481,7 @@ __global__ __launch_bounds__(64 * W) void two_means_quad_kernel(const float *__r
             for (int s = 0; s < NS; s++) ps[s] = cbuf[par][soff + s * WAVE];
             pp = reg_dot<NV>(p, p);
             ic++;
+            r2p = tm_recip(ic + 1);
         } else if (upd == 2) {
 #pragma unroll
             for (int kk = 0; kk < NV; kk++) q[kk] = cbuf[par][kk * WAVE + lane];
@@ -437,10 +489,11 @@ __global__ __launch_bounds__(64 * W) void two_means_quad_kernel(const float *__r
             for (int s = 0; s < NS; s++) qs[s] = cbuf[par][soff + s * WAVE];
             qq = reg_dot<NV>(q, q);
             jc++;
+            r2q = tm_recip(jc + 1);
         }
         it2 = it3;
-        nk2 = nk2_1;
-        nk2_1 = nk2_2;
+        ri = ri_1;
+        ri_1 = ri_2;
     }
     (void)it1;
     if (w != 0) return;
@@ -997,7 +1050,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 const int nvq = (dpad / 4 + WAVE - 1) / WAVE;   // float4 per lane per row
                 const unsigned wg = (unsigned)((A + 3) / 4);
 #define TMW_LAUNCH(NVV)                                                                                              \
-    hipLaunchKernelGGL(two_means_wave_kernel<NVV>, dim3(wg), dim3(256), 0, h->stream, h->X.p, h->norm2.p, N, dpad, \
+    hipLaunchKernelGGL(two_means_wave_kernel<NVV>, dim3(wg), dim3(256), 0, h->stream, h->X.p, h->rowinfo.p, N, dpad, \
                        h->perm.p, d_tasks.p, A, seed, hp_level)
                 // Four waves per node while the level's nodes fit the chip at once (2 workgroups per CU): the
                 // node's 200-step chain is then ~1.6x shorter (C3: 0.45 / 0.62 ms instead of 0.73 / 0.75 ms at
@@ -1007,7 +1060,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 static const bool tm_quad_on = !(getenv("MORNA_TM_QUAD") && atoi(getenv("MORNA_TM_QUAD")) == 0);
                 const bool tm_quad = tm_quad_on && A <= 2 * h->n_cus;
 #define TMQ_LAUNCH(NVV)                                                                                                 \
-    hipLaunchKernelGGL((two_means_quad_kernel<NVV, 4>), dim3((unsigned)A), dim3(256), 0, h->stream, h->X.p, h->norm2.p, \
+    hipLaunchKernelGGL((two_means_quad_kernel<NVV, 4>), dim3((unsigned)A), dim3(256), 0, h->stream, h->X.p, h->rowinfo.p, \
                        N, dpad, h->perm.p, d_tasks.p, seed, hp_level)
                 if (tm_quad && nvq == 12) TMQ_LAUNCH(12);
                 else if (tm_quad && nvq == 8) TMQ_LAUNCH(8);

@@ -279,6 +279,31 @@ def test_forest_bit_exact_vs_oracle_wave_order(capi, f, N, T):
         assert d[qi, :int(cnt[qi])].tobytes() == np.array(rd, np.float32).tobytes()
 
 
+@pytest.mark.parametrize("f,N,T", [(40, 3000, 6), (1000, 2500, 2), (3000, 7000, 2)])
+def test_forest_subnormal_centroid_elements(capi, f, N, T):
+    """Columns scaled down to the bottom of the float range: x / |x| and (c * n + x / |x|) / (n + 1) land among the
+    subnormals, where a quotient CAN be an exact rounding tie.  two_means takes its quotients through fp64
+    reciprocals and must notice these cases and divide for real (devutil.hpp centroid_step4); the oracle divides."""
+    from morna_amd.annoy import AnnoyIndex
+    rng = np.random.default_rng(424242 + f)
+    X = _clustered(rng, N, f).astype(np.float64)
+    q = f // 4
+    X[:, :q] *= 2.0 ** rng.integers(-146, -132, q)          # subnormal inputs, a few significant bits each
+    X[:, q:2 * q] *= 2.0 ** rng.integers(-126, -120, q)     # normal inputs whose quotient by |x| is subnormal
+    X = X.astype(np.float32)
+    assert (np.abs(X[:, :q]) < 1.2e-38).all() and (X[:, :q] != 0).any()
+    o = capi.AnnoyOracle(f, mode=1)
+    o.set_items(X)
+    o.build(T)
+    a = AnnoyIndex(f)
+    a.add_items(X)
+    a.build(T)
+    _compare_forest(a, o, N, T)
+    hp = a.get_forest()["hyperplanes"]
+    tiny = np.abs(hp[:, :2 * q])
+    assert ((tiny > 0) & (tiny < 1.2e-38)).any()            # the case under test did occur
+
+
 def test_forest_degenerate_inputs(capi):
     """All rows identical (every split is 100% imbalanced -> random fallback) and
     a matrix of zeros (every margin is exactly 0 -> coin flips)."""
