@@ -132,19 +132,26 @@ __device__ inline T vgather(const T *base, uint32_t i)
 }
 
 // One step of annoy's two_means centroid update for four elements, (c * n + x / |x|) / (n + 1), every
-// operation rounded to fp32 as the scalar code rounds it.  The two quotients are taken through fp64
-// reciprocals, r1 = RN64(1 / |x|), r2 = RN64(1 / (n + 1)): a quotient a / b of two floats is never exactly
-// on, nor within 2^-49 (relative) of, a rounding boundary of float (a - b * mid is a non-zero multiple of
-// ulp(b) * ulp(mid) for every midpoint mid), and RN64(a * RN64(1 / b)) is within 2^-52 of a / b, so its
-// nearest float IS RN32(a / b).  Below the normal range the spacing of floats is fixed and a quotient CAN be an
-// exact tie; a / b then lies between two subnormals (or a subnormal and FLT_MIN or 0) and ties-to-even picks
-// the even one, while the fp64 route returns one of the two: when it is wrong it has returned the odd one, a
-// non-zero subnormal.  (Away from a tie the distance argument holds a fortiori.)  So a result that is not a
-// non-zero subnormal is right, and the rare steps with one are recomputed with real divisions (the branch is
-// wave-uniform; kernels run with fp32 denormals on).  Whether x / |x| can be subnormal at all is a property of
-// the row, found once when its norm is taken (RowInfo): such rows take the real divisions for the whole step
-// (`force`), and only the second quotient is looked at here.
-// All 64 lanes must call.
+// operation rounded to fp32 as the scalar code rounds it, without the two IEEE division sequences per element.
+//
+// x / |x| goes through the fp64 reciprocal r1 = RN64(1 / |x|) (RowInfo): a quotient a / b of two floats is never
+// exactly on, nor within 2^-49 (relative) of, a rounding boundary of float (a - b * mid is a non-zero multiple
+// of ulp(b) * ulp(mid) for every midpoint mid), and RN64(a * r1) is within 2^-52 of a / b, so its nearest float
+// IS RN32(a / b).  Below the normal range the spacing of floats is fixed and a quotient CAN be an exact tie;
+// whether x_i / |x| can land there at all is a property of the row, found once when its norm is taken: such
+// rows take the real divisions for the whole step (`force`).
+//
+// t / (n + 1), a division by a small integer m <= 202, stays in fp32: with y = RN32(1 / m), q = RN(t * y) is
+// within ~2 ulp of t / m; e = q * m - t is then a multiple of ulp(q) no larger than ~400 ulp(q): the FMA
+// delivers it exactly; and q - e * y differs from t / m by at most |e| / m * 2^-24 <= 2^-23 ulp(q), while t / m
+// keeps at least ulp(q) / (2 m) away from every rounding boundary (t - m * mid is a non-zero multiple of half
+// an ulp): o = RN(q - e * y) IS RN32(t / m).  Written as fma(q, m, -t) and fma(-e, y, q) the zero results keep
+// the sign of t.  The argument needs finite operands and a normal result.  At an exact tie below FLT_MIN the
+// route returns one of the two neighbours, and when it is the wrong (odd) one that is a non-zero subnormal; a
+// non-finite t gives NaN.  So a result that is neither subnormal nor non-finite is right, and the rare others
+// are recomputed with real divisions (wave-uniform branch, laid out off the hot path; kernels run with fp32
+// denormals on).  All 64 lanes must call.  Three packed operations per two elements instead of six.
+
 // the step as written: two real divisions per element
 __device__ inline float4 centroid_div4(const float4 c, const float4 x, float f0, float f1, float norm)
 {
@@ -155,29 +162,30 @@ __device__ inline float4 centroid_div4(const float4 c, const float4 x, float f0,
     o.w = (c.w * f0 + x.w / norm) / f1;
     return o;
 }
-// lanes whose v is a non-zero subnormal: one v_cmp_class_f32 straight into a lane mask (the bool route through
-// __builtin_amdgcn_classf + ballot costs two more VALU operations per value)
-__device__ inline unsigned long long subnormal_lanes(float v)
+// lanes whose v is a non-zero subnormal, an infinity or a NaN: one v_cmp_class_f32 straight into a lane mask
+// (the bool route through __builtin_amdgcn_classf + ballot costs two more VALU operations per value)
+__device__ inline unsigned long long suspect_lanes(float v)
 {
     unsigned long long m;
-    asm("v_cmp_class_f32_e64 %0, %1, %2" : "=s"(m) : "v"(v), "s"(0x90));   // 0x90: -denormal | +denormal
+    asm("v_cmp_class_f32_e64 %0, %1, %2" : "=s"(m) : "v"(v), "s"(0x297));   // NaNs | infinities | denormals
     return m;
 }
-// `force`: all ones for a row whose RowInfo says x / |x| may have a subnormal element (real divisions for the
-// whole step), else 0 -- one more scalar OR, and a single definition of the new centroid for the compiler
+// r1 = RN64(1 / norm), y = RN32(1 / f1); `force`: all ones for a row whose x / |x| may have a subnormal element
 __device__ inline float4 centroid_step4(const float4 c, const float4 x, float f0, float f1, float norm, double r1,
-                                        double r2, unsigned long long force)
+                                        float y, unsigned long long force)
 {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     const float nx = (float)((double)x.x * r1), ny = (float)((double)x.y * r1);
     const float nz = (float)((double)x.z * r1), nw = (float)((double)x.w * r1);
-    const float tx = c.x * f0 + nx, ty = c.y * f0 + ny, tz = c.z * f0 + nz, tw = c.w * f0 + nw;
-    float4 o;
-    o.x = (float)((double)tx * r2);
-    o.y = (float)((double)ty * r2);
-    o.z = (float)((double)tz * r2);
-    o.w = (float)((double)tw * r2);
-    const unsigned long long sus = ((subnormal_lanes(o.x) | subnormal_lanes(o.y)) | (subnormal_lanes(o.z) | subnormal_lanes(o.w))) | force;
-    if (__builtin_expect(sus != 0, 0)) o = centroid_div4(c, x, f0, f1, norm);   // wave-uniform, and laid out off the hot path
+    const f32x2 f02 = {f0, f0}, m2 = {f1, f1}, y2 = {y, y};
+    const f32x2 t01 = (f32x2){c.x, c.y} * f02 + (f32x2){nx, ny};   // two roundings each (-ffp-contract=off)
+    const f32x2 t23 = (f32x2){c.z, c.w} * f02 + (f32x2){nz, nw};
+    const f32x2 q01 = t01 * y2, q23 = t23 * y2;
+    const f32x2 e01 = __builtin_elementwise_fma(q01, m2, -t01), e23 = __builtin_elementwise_fma(q23, m2, -t23);
+    const f32x2 o01 = __builtin_elementwise_fma(-e01, y2, q01), o23 = __builtin_elementwise_fma(-e23, y2, q23);
+    float4 o = make_float4(o01.x, o01.y, o23.x, o23.y);
+    const unsigned long long sus = ((suspect_lanes(o.x) | suspect_lanes(o.y)) | (suspect_lanes(o.z) | suspect_lanes(o.w))) | force;
+    if (__builtin_expect(sus != 0, 0)) o = centroid_div4(c, x, f0, f1, norm);   // wave-uniform
     return o;
 }
 

@@ -9,9 +9,10 @@
 //   two_means_wave_kernel  one WAVE per split node, centroids / current row / next
 //                     row in registers: 200 sequential centroid updates, the row of
 //                     step l+1 in flight during step l (the Kiss32 stream does not
-//                     depend on data).  two_means_quad_kernel: four waves per node,
-//                     each updating a quarter of the centroid, for levels whose nodes fit
-//                     the chip at once.  two_means_kernel: the LDS form (one workgroup
+//                     depend on data; it arrives by LDS-DMA).  two_means_strip_kernel:
+//                     four waves per node, each owning 16 of the 64 canonical lanes of every
+//                     dot product and that strip of the centroids, for levels whose nodes
+//                     fit the chip at once.  two_means_kernel: the LDS form (one workgroup
 //                     per node) for rows too long for the register file.
 //   (splitmm.hip)     the sides of the whole level as one fp16 MFMA product that filters,
 //                     exact fp32 dots for the pairs it cannot decide -- the form that runs
@@ -41,6 +42,7 @@ namespace morna {
 
 #define TM_THREADS 256
 #define TM_ITERS 200
+#define TM_STRIP_DEPTH 4   // rows in flight per node in two_means_strip_kernel
 
 // ------------------------------------------------------------------ two_means
 
@@ -217,17 +219,17 @@ __device__ inline void reg_normalize(float4 (&v)[NV])
     }
 }
 
-// RN64(1 / n) for the counts a centroid can reach in TM_ITERS steps (1 + 200, then + 1): the same correctly
-// rounded quotient the step would compute, folded by the compiler and read through the scalar cache.
+// RN32(1 / n) for the counts a centroid can reach in TM_ITERS steps (1 + 200, then + 1): folded by the compiler,
+// read through the scalar cache when a count changes.
 struct RecipTable {
-    double v[TM_ITERS + 8];
+    float v[TM_ITERS + 8];
     constexpr RecipTable() : v()
     {
-        for (int n = 1; n < TM_ITERS + 8; n++) v[n] = 1.0 / (double)n;
+        for (int n = 1; n < TM_ITERS + 8; n++) v[n] = 1.0f / (float)n;
     }
 };
 __constant__ RecipTable k_recip = RecipTable();
-__device__ inline double tm_recip(int n) { return k_recip.v[__builtin_amdgcn_readfirstlane(n)]; }   // n is wave-uniform
+__device__ inline float tm_recip(int n) { return k_recip.v[__builtin_amdgcn_readfirstlane(n)]; }   // n is wave-uniform
 
 // One wave per node: both centroids and the current row in registers (3 x NV float4 per lane).  The row of the
 // NEXT step is fetched by LDS-DMA (global_load_lds, no destination registers) at the top of a step and read into
@@ -235,7 +237,7 @@ __device__ inline double tm_recip(int n) { return k_recip.v[__builtin_amdgcn_rea
 // and 24 v_mov per step) does not fit two waves per SIMD without spilling, and a spill inside this loop waits
 // for the whole prefetch (vmcnt is counted in order).
 template <int NV>
-__global__ __launch_bounds__(256, 2) void two_means_wave_kernel(const float *__restrict__ X, const RowInfo *__restrict__ rowinfo,
+__global__ __launch_bounds__(256, 3) void two_means_wave_kernel(const float *__restrict__ X, const RowInfo *__restrict__ rowinfo,
                                                              int64_t n_items, int32_t dpad,
                                                              const int32_t *__restrict__ perm,
                                                              const SplitTask *__restrict__ tasks, int32_t n_tasks,
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void two_means_wave_kernel(const float *__r
     float4 *xl = xnext[wv];
 
     int ic = 1, jc = 1;
-    double r2p = tm_recip(2), r2q = tm_recip(2);   // 1 / (ic + 1), 1 / (jc + 1), fetched when the count changes
+    float r2p = tm_recip(2), r2q = tm_recip(2);   // RN32 of 1 / (ic + 1), 1 / (jc + 1), fetched when the count changes
     for (int l = 0; l < TM_ITERS; l++) {
         // this step's row: what was requested a step ago, now wave-uniform values in scalar registers
         const float nk2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(riv.norm2)));
@@ -339,171 +341,190 @@ __global__ __launch_bounds__(256, 2) void two_means_wave_kernel(const float *__r
     for (int kk = 0; kk < NV; kk++) out[lane + kk * WAVE] = p[kk];
 }
 
-// ---- two_means, FOUR waves per node ---------------------------------------------------
-// The 200 steps of a node are one dependent chain, and most of a step is elementwise: the
-// IEEE divisions of the centroid update, (c * n + x / |x|) / (n + 1), 96 per lane.  Here
-// every wave of a 4-wave workgroup keeps p and q in registers and makes the same decision
-// from the same dots, but updates only ITS quarter of the chosen centroid and fetches only its
-// quarter of the coming rows; quarters are exchanged through LDS (one barrier per step, buffers
-// alternate).  The Kiss32 stream does not depend on data, so the row index is fetched three
-// steps ahead and the row two steps ahead: no step waits for the index -> row load chain.
-// Same operations on the same values as two_means_wave_kernel.
-
-// this wave's share of centroid c, picked with selects (w is wave-uniform): indexing the register
-// array with w, or passing it to a function per value of w, would move it to scratch memory
-template <int NV, int W>
-__device__ inline float4 quad_pick(const float4 (&c)[NV], int w, int s)
+// ---- two_means, four waves per node, by STRIPS of the canonical lanes ----------------------
+// The shallow levels have fewer nodes than the chip has SIMDs and every node is one dependent chain of 200
+// steps: what counts is the length of a step.  Here wave w of a node's workgroup owns the canonical lanes
+// 16 w .. 16 w + 15 of every dot product: its lane l holds, for each 256-float k-step, element 64 w + l of the
+// two centroids and of the row, i.e. chain (l & 3) of canonical lane 16 w + (l >> 2).  A dot is then
+//   * the lane's ONE fmaf chain over the k-steps (the same chain wave_dot runs, four to a lane),
+//   * the fold (a0 + a1) + (a2 + a3) across four neighbouring lanes (two DPP quad permutes),
+//   * 64 folded values through LDS (one barrier), after which every wave runs the canonical butterfly on all of
+//     them and holds the same result: same operations on the same values as wave_dot, bit for bit.
+// Nothing else is exchanged and nothing is computed twice except the butterfly and the scalar distance
+// arithmetic: a wave updates only its strip of the chosen centroid (12 elements per lane at D = 3000) and never
+// sees the rest.  The dots of step l+1 (and the self-dot of the centroid just updated) are folded right after
+// the update of step l, so a step has ONE barrier.  Rows are fetched DEPTH steps ahead into a register ring
+// (a strip of a row is 12 registers), their index and RowInfo likewise: a step is several times shorter than an
+// HBM round trip.  The loop is unrolled DEPTH times so that ring slots are compile-time registers.
+template <int NV, int DEPTH>
+__global__ __launch_bounds__(256) void two_means_strip_kernel(const float *__restrict__ X, const RowInfo *__restrict__ rowinfo,
+                                                            int64_t n_items, int32_t dpad,
+                                                            const int32_t *__restrict__ perm,
+                                                            const SplitTask *__restrict__ tasks, uint32_t seed,
+                                                            float *__restrict__ hp)
 {
-    constexpr int NS = NV / W;
-    float4 r = c[s];
-#pragma unroll
-    for (int ww = 1; ww < W; ww++) {
-        const float4 v = c[ww * NS + s];
-        EW4(r, w == ww ? v.x : r.x, w == ww ? v.y : r.y, w == ww ? v.z : r.z, w == ww ? v.w : r.w);
-    }
-    return r;
-}
-
-// W waves per node.  W = 4 is what runs: with one wave per float4 of a lane's share (W = NV = 12) every wave still
-// does both dots, both distances and the full read-back of the centroid, and twelve waves meet at the barrier:
-// 0.61 ms instead of 0.44 ms at the root level of C3.
-template <int NV, int W>
-__global__ __launch_bounds__(64 * W) void two_means_quad_kernel(const float *__restrict__ X, const RowInfo *__restrict__ rowinfo,
-                                                             int64_t n_items, int32_t dpad,
-                                                             const int32_t *__restrict__ perm,
-                                                             const SplitTask *__restrict__ tasks, uint32_t seed,
-                                                             float *__restrict__ hp)
-{
-    static_assert(NV % W == 0, "a wave owns NV / W float4 per lane");
-    constexpr int NS = NV / W;
-    __shared__ float4 rbuf[2][NV * WAVE];   // the row of step l sits in rbuf[l & 1]
-    __shared__ float4 cbuf[2][NV * WAVE];   // the centroid updated in step l, cbuf[l & 1]
+    static_assert(NV % 4 == 0, "the update works on groups of four k-steps");
+    static_assert(TM_ITERS % DEPTH == 0, "the step loop is unrolled DEPTH times");
+    constexpr int NS = NV / 4;
+    __shared__ float ex[2][3][WAVE];   // folded values of up to three dots per canonical lane, by exchange parity
 
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    const int L = 16 * w + (lane >> 2);   // the canonical lane this lane's chain belongs to
     const SplitTask t = tasks[blockIdx.x];
-    const int nvec = dpad / 4;
     const int32_t *items = perm + (int64_t)t.tree * n_items + t.start;
     // every wave runs the node's Kiss32 stream itself: no index is exchanged
     Kiss32 rng(node_seed(seed, (uint32_t)t.tree, (uint32_t)t.level, (uint32_t)t.start, (uint32_t)t.attempt));
+    const float *Xs = X + 64 * w + lane;   // this lane's element of k-step 0 of row 0
+
+    // this lane's strip of a row: element 64 w + l of each k-step, four k-steps to a float4
+    auto load_strip = [&](int32_t it, float4 (&dst)[NS]) {
+        const float *r = Xs + (int64_t)it * dpad;
+#pragma unroll
+        for (int s = 0; s < NS; s++) EW4(dst[s], r[(4 * s) * 256], r[(4 * s + 1) * 256], r[(4 * s + 2) * 256], r[(4 * s + 3) * 256]);
+    };
+    // the lane's chain of a canonical dot: fmaf over the k-steps in order, from 0
+    auto chain = [&](const float4 (&a)[NS], const float4 (&b)[NS]) {
+        float acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            acc = fmaf(a[s].x, b[s].x, acc);
+            acc = fmaf(a[s].y, b[s].y, acc);
+            acc = fmaf(a[s].z, b[s].z, acc);
+            acc = fmaf(a[s].w, b[s].w, acc);
+        }
+        return acc;
+    };
+    int xpar = 0;
+    // up to three dots at once: fold, exchange, butterfly.  Results in lanes 0 / 16 / 32 of the return value.
+    auto exchange3 = [&](float a, float b, float c) {
+        // (a0 + a1) + (a2 + a3) over the four chains of a canonical lane (quad_perm [1,0,3,2], then [2,3,0,1])
+        a = a + dpp_move<0xB1>(a);
+        b = b + dpp_move<0xB1>(b);
+        c = c + dpp_move<0xB1>(c);
+        a = a + dpp_move<0x4E>(a);
+        b = b + dpp_move<0x4E>(b);
+        c = c + dpp_move<0x4E>(c);
+        if ((lane & 3) == 0) {
+            ex[xpar][0][L] = a;
+            ex[xpar][1][L] = b;
+            ex[xpar][2][L] = c;
+        }
+        __syncthreads();
+        const float f[3] = {ex[xpar][0][lane], ex[xpar][1][lane], ex[xpar][2][lane]};
+        xpar ^= 1;   // the next exchange writes the other buffer: a wave may still be reading this one
+        return wave_sum_multi<3>(f, lane);
+    };
+    auto lane_value = [](float u, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u), l)); };
 
     uint32_t i = rng.index((uint32_t)t.count);
     uint32_t j = rng.index((uint32_t)t.count - 1u);
     j += (j >= i);
-    float4 p[NV], q[NV];
-    reg_load_row<NV>(X + (int64_t)items[i] * dpad, nvec, lane, p);
-    reg_load_row<NV>(X + (int64_t)items[j] * dpad, nvec, lane, q);
-    reg_normalize<NV>(p);
-    reg_normalize<NV>(q);
-    float pp = reg_dot<NV>(p, p), qq = reg_dot<NV>(q, q);
-
-    // rows of steps 0, 1, 2 (draws beyond step 199 are never used: the stream is the node's own)
-    const int32_t it0 = items[rng.index((uint32_t)t.count)];
-    int32_t it1 = items[rng.index((uint32_t)t.count)];
-    int32_t it2 = items[rng.index((uint32_t)t.count)];
-    const int soff = (w * NS) * WAVE + lane;   // this wave's quarter of a row
-    // this wave's quarter of each centroid, kept beside the full copies: the update reads it without
-    // having to pick it out of the register array by the (run-time) wave number at every step
-    float4 ps[NS], qs[NS];
+    float4 p[NS], q[NS];
+    load_strip(items[i], p);
+    load_strip(items[j], q);
+    {   // normalise both (reg_normalize), then their self-dots
+        const float u = exchange3(chain(p, p), chain(q, q), 0.f);
+        const float np = sqrtf(lane_value(u, 0)), nq = sqrtf(lane_value(u, 16));
+        if (np > 0.f) {
 #pragma unroll
-    for (int s = 0; s < NS; s++) {
-        ps[s] = quad_pick<NV, W>(p, w, s);
-        qs[s] = quad_pick<NV, W>(q, w, s);
-    }
-    float4 xs1[NS];
+            for (int s = 0; s < NS; s++) EW4(p[s], p[s].x / np, p[s].y / np, p[s].z / np, p[s].w / np);
+        }
+        if (nq > 0.f) {
 #pragma unroll
-    for (int s = 0; s < NS; s++) xs1[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-    {
-        const float4 *x0 = (const float4 *)(X + (int64_t)it0 * dpad) + soff;
-        const float4 *x1 = (const float4 *)(X + (int64_t)it1 * dpad) + soff;
-#pragma unroll
-        for (int s = 0; s < NS; s++) {
-            rbuf[0][soff + s * WAVE] = x0[s * WAVE];
-            xs1[s] = x1[s * WAVE];
+            for (int s = 0; s < NS; s++) EW4(q[s], q[s].x / nq, q[s].y / nq, q[s].z / nq, q[s].w / nq);
         }
     }
-    RowInfo ri = rowinfo[it0], ri_1 = rowinfo[it1];
-    __syncthreads();
+    float pp, qq;
+    {
+        const float u = exchange3(chain(p, p), chain(q, q), 0.f);
+        pp = lane_value(u, 0);
+        qq = lane_value(u, 16);
+    }
+
+    // ring slot r holds the row of step l with l % DEPTH == r, its item id and its RowInfo (still vector registers
+    // when they arrive; made scalar when used); it_ahead is the item of the step DEPTH ahead of the one running
+    float4 x[DEPTH][NS];
+    RowInfo ri[DEPTH];
+#pragma unroll
+    for (int r = 0; r < DEPTH; r++) {
+        const int32_t it = items[rng.index((uint32_t)t.count)];
+        load_strip(it, x[r]);
+        ri[r] = rowinfo[it];
+    }
+    int32_t it_ahead = vgather(items, rng.index((uint32_t)t.count));
 
     int ic = 1, jc = 1;
-    double r2p = tm_recip(2), r2q = tm_recip(2);   // 1 / (ic + 1), 1 / (jc + 1), fetched when the count changes
-    for (int l = 0; l < TM_ITERS; l++) {
-        const int par = l & 1;
-        const float4 *xrow = rbuf[par];
-        // row l+1 (requested a step ago) goes to the other buffer -- nobody reads it after the last
-        // barrier -- and the same registers then receive this wave's quarter of row l+2; the index of
-        // row l+3 and the norm of row l+2 are requested as well
+    float r2p = tm_recip(2), r2q = tm_recip(2);   // RN32 of 1 / (ic + 1), 1 / (jc + 1)
+    float u = exchange3(chain(p, x[0]), chain(q, x[0]), 0.f);   // the dots of step 0
+    int upd_prev = 0;
+    for (int l0 = 0; l0 < TM_ITERS; l0 += DEPTH) {
 #pragma unroll
-        for (int s = 0; s < NS; s++) rbuf[par ^ 1][soff + s * WAVE] = xs1[s];
-        const int32_t it3 = vgather(items, rng.index((uint32_t)t.count));
-        {
-            const float4 *x2 = (const float4 *)(X + (int64_t)it2 * dpad) + soff;
+        for (int r = 0; r < DEPTH; r++) {
+            // ---- decide (every wave: same values, same decision)
+            if (upd_prev == 1) pp = lane_value(u, 32);
+            if (upd_prev == 2) qq = lane_value(u, 32);
+            const float nk2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ri[r].norm2)));
+            const int norm_bits = __builtin_amdgcn_readfirstlane(__float_as_int(ri[r].norm));
+            const long long r1_bits = ((long long)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(ri[r].rnorm) >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)__double_as_longlong(ri[r].rnorm));
+            const float di = (float)ic * ang_dist(pp, nk2, lane_value(u, 0));
+            const float dj = (float)jc * ang_dist(qq, nk2, lane_value(u, 16));
+            const float norm = __int_as_float(norm_bits & 0x7fffffff);   // sqrtf(nk2)
+            const unsigned long long force = norm_bits < 0 ? ~0ull : 0ull;
+            const double r1 = __longlong_as_double(r1_bits);
+            int upd = 0;
+            if (norm > 0.f) upd = di < dj ? 1 : (dj < di ? 2 : 0);
+            // ---- update this wave's strip of the chosen centroid, and its chain of the new self-dot
+            float cc = 0.f;
+            if (upd == 1) {
+                const float f0 = (float)ic, f1 = (float)(ic + 1);
 #pragma unroll
-            for (int s = 0; s < NS; s++) xs1[s] = x2[s * WAVE];
-        }
-        const RowInfo ri_2 = vgather(rowinfo, (uint32_t)it2);
-        const float nk2 = ri.norm2;
-        // both dots against the row in LDS, reduced together (p.x in lane 0, q.x in lane 32)
-        Acc4 a = acc4_zero(), b = acc4_zero();
-#pragma unroll
-        for (int k = 0; k < NV; k++) {
-            const float4 xv = xrow[k * WAVE + lane];
-            fma4(a, p[k], xv);
-            fma4(b, q[k], xv);
-        }
-        const float f[2] = {(a.lo.x + a.lo.y) + (a.hi.x + a.hi.y), (b.lo.x + b.lo.y) + (b.hi.x + b.hi.y)};
-        const float u = wave_sum_multi<2>(f, lane);
-        const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u), 0));
-        const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u), 32));
-        const float di = (float)ic * ang_dist(pp, nk2, px);
-        const float dj = (float)jc * ang_dist(qq, nk2, qx);
-        const float norm = fabsf(ri.norm);   // sqrtf(nk2)
-        // x / norm may be subnormal somewhere in this row: real divisions for the step
-        const unsigned long long force = __builtin_amdgcn_readfirstlane(__float_as_int(ri.norm)) < 0 ? ~0ull : 0ull;
-        int upd = 0;   // the same in all four waves
-        if (norm > 0.f) upd = di < dj ? 1 : (dj < di ? 2 : 0);
-        if (upd) {
-            const float f0 = upd == 1 ? (float)ic : (float)jc, f1 = f0 + 1.f;   // counts are small integers: exact
-            const double r1 = ri.rnorm, r2 = upd == 1 ? r2p : r2q;
-#pragma unroll
-            for (int s = 0; s < NS; s++) {
-                float4 c;
-                EW4(c, upd == 1 ? ps[s].x : qs[s].x, upd == 1 ? ps[s].y : qs[s].y, upd == 1 ? ps[s].z : qs[s].z,
-                    upd == 1 ? ps[s].w : qs[s].w);
-                const float4 xv = xrow[soff + s * WAVE];
-                cbuf[par][soff + s * WAVE] = centroid_step4(c, xv, f0, f1, norm, r1, r2, force);
+                for (int s = 0; s < NS; s++) p[s] = centroid_step4(p[s], x[r][s], f0, f1, norm, r1, r2p, force);
+                cc = chain(p, p);
+                ic++;
+                r2p = tm_recip(ic + 1);
             }
+            if (upd == 2) {
+                const float f0 = (float)jc, f1 = (float)(jc + 1);
+#pragma unroll
+                for (int s = 0; s < NS; s++) q[s] = centroid_step4(q[s], x[r][s], f0, f1, norm, r1, r2q, force);
+                cc = chain(q, q);
+                jc++;
+                r2q = tm_recip(jc + 1);
+            }
+            upd_prev = upd;
+            // ---- slot r is free: the row DEPTH steps ahead goes there.  (Past step 199 these fetch rows nobody
+            // uses: the stream has more draws and every index is valid.)
+            const int32_t it_new = it_ahead;
+            load_strip(it_new, x[r]);
+            ri[r] = vgather(rowinfo, (uint32_t)it_new);
+            it_ahead = vgather(items, rng.index((uint32_t)t.count));
+            // ---- the dots of the next step, with the row in the next slot
+            constexpr int DUMMY = 0;
+            (void)DUMMY;
+            const int rn = (r + 1) % DEPTH;
+            u = exchange3(chain(p, x[rn]), chain(q, x[rn]), cc);
         }
-        __syncthreads();
-        if (upd == 1) {
-#pragma unroll
-            for (int kk = 0; kk < NV; kk++) p[kk] = cbuf[par][kk * WAVE + lane];
-#pragma unroll
-            for (int s = 0; s < NS; s++) ps[s] = cbuf[par][soff + s * WAVE];
-            pp = reg_dot<NV>(p, p);
-            ic++;
-            r2p = tm_recip(ic + 1);
-        } else if (upd == 2) {
-#pragma unroll
-            for (int kk = 0; kk < NV; kk++) q[kk] = cbuf[par][kk * WAVE + lane];
-#pragma unroll
-            for (int s = 0; s < NS; s++) qs[s] = cbuf[par][soff + s * WAVE];
-            qq = reg_dot<NV>(q, q);
-            jc++;
-            r2q = tm_recip(jc + 1);
-        }
-        it2 = it3;
-        ri = ri_1;
-        ri_1 = ri_2;
     }
-    (void)it1;
-    if (w != 0) return;
-    // create_split: n = normalize(p - q)
+    // create_split: n = normalize(p - q), each wave its strip
 #pragma unroll
-    for (int kk = 0; kk < NV; kk++) EW4(p[kk], p[kk].x - q[kk].x, p[kk].y - q[kk].y, p[kk].z - q[kk].z, p[kk].w - q[kk].w);
-    reg_normalize<NV>(p);
-    float4 *out = (float4 *)(hp + (int64_t)t.slot * dpad);
+    for (int s = 0; s < NS; s++) EW4(p[s], p[s].x - q[s].x, p[s].y - q[s].y, p[s].z - q[s].z, p[s].w - q[s].w);
+    {
+        const float un = exchange3(chain(p, p), 0.f, 0.f);
+        const float nn = sqrtf(lane_value(un, 0));
+        if (nn > 0.f) {
 #pragma unroll
-    for (int kk = 0; kk < NV; kk++) out[lane + kk * WAVE] = p[kk];
+            for (int s = 0; s < NS; s++) EW4(p[s], p[s].x / nn, p[s].y / nn, p[s].z / nn, p[s].w / nn);
+        }
+    }
+    float *out = hp + (int64_t)t.slot * dpad + 64 * w + lane;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        out[(4 * s) * 256] = p[s].x;
+        out[(4 * s + 1) * 256] = p[s].y;
+        out[(4 * s + 2) * 256] = p[s].z;
+        out[(4 * s + 3) * 256] = p[s].w;
+    }
 }
 
 // ---------------------------------------------------------------- split kernel
@@ -820,7 +841,19 @@ __global__ __launch_bounds__(256) void fallback_kernel(const SplitTask *__restri
     }
 }
 
-// stable partition of one segment by side; one workgroup per node (PT threads: 1024 while nodes are large)
+// annoy's rule for the sides of one attempt (_make_tree): attempts 0 and 1 stand when the imbalance is below 0.95,
+// the last attempt (2) unless it is above 0.99 (then the node gets random sides: tasks of "attempt" 3, which always
+// stand).  The host driver applies the same expressions to the same counts.
+__host__ __device__ inline bool sides_stand(int attempt, int64_t n0, int64_t n1)
+{
+    if (attempt >= 3) return true;
+    const double imb = split_imbalance(n0, n1);
+    return attempt == 2 ? !(imb > 0.99) : imb < 0.95;
+}
+
+// stable partition of one segment by side; one workgroup per node (PT threads: 1024 while nodes are large).
+// Launched right behind the split of every attempt, before the host has seen the counts: a node whose sides do
+// not stand is left alone (its next attempt, or the fallback, partitions it).
 template <int PT>
 __global__ __launch_bounds__(PT) void partition_kernel(const SplitTask *__restrict__ tasks, int64_t n_items,
                                                        const uint8_t *__restrict__ side,
@@ -831,6 +864,7 @@ __global__ __launch_bounds__(PT) void partition_kernel(const SplitTask *__restri
     const SplitTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const int n1 = ones[blockIdx.x], n0 = t.count - n1;
+    if (!sides_stand(t.attempt, n0, n1)) return;   // uniform over the workgroup
     const int64_t base = (int64_t)t.tree * n_items + t.start;
     int run0 = 0, run1 = 0;   // items already placed on each side
     for (int p0 = 0; p0 < t.count; p0 += PT) {
@@ -937,11 +971,9 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
     int rc = MORNA_OK;
     std::vector<SplitTask> tasks;
     std::vector<int32_t> h_ones;
-    std::vector<std::vector<SplitTask>> kept_tasks;   // host arguments of launches the host did not wait for
-    std::vector<std::vector<int32_t>> kept_ones;
     int32_t level = 0;
 
-    auto cleanup = [&]() { (void)hipStreamSynchronize(h->stream); };   // kept host arguments may still be in flight
+    auto cleanup = [&]() { (void)hipStreamSynchronize(h->stream); };   // the last partition may still be running
 #define F_TRY(e)                                                    \
     do {                                                            \
         hipError_t _e = (e);                                        \
@@ -994,9 +1026,35 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             return chunk;
         };
 
-        int attempts_run = 0;
+        // Partition of the nodes whose sides stand, enqueued right behind the kernels that wrote the sides and their
+        // counts (d_tasks / d_ones as they are on the device).  The counts travel to the host on the side stream,
+        // from the moment the split is done: the host's bookkeeping for the next attempt or level runs while the
+        // partition does.
+        auto partition_and_fetch_counts = [&](int32_t A, int64_t level_rows) -> int {
+            if (hipEventRecord(h->ev_fork, h->stream) != hipSuccess || hipStreamWaitEvent(h->stream2, h->ev_fork, 0) != hipSuccess) {
+                set_error("forest build: event hand-over to the side stream failed");
+                return MORNA_E_HIP;
+            }
+            {
+                ScopedTimer tm(h, MORNA_T_PARTITION, 0);
+                if (level_rows >= (int64_t)A * 2048)
+                    hipLaunchKernelGGL(partition_kernel<1024>, dim3((unsigned)A), dim3(1024), 0, h->stream, d_tasks.p, N, side.p,
+                                       d_ones.p, h->perm.p, tmp.p);
+                else
+                    hipLaunchKernelGGL(partition_kernel<256>, dim3((unsigned)A), dim3(256), 0, h->stream, d_tasks.p, N, side.p,
+                                       d_ones.p, h->perm.p, tmp.p);
+            }
+            h_ones.resize((size_t)A);
+            if (hipGetLastError() != hipSuccess ||
+                hipMemcpyAsync(h_ones.data(), d_ones.p, (size_t)A * 4, hipMemcpyDeviceToHost, h->stream2) != hipSuccess ||
+                hipStreamSynchronize(h->stream2) != hipSuccess) {
+                set_error("forest build: partition launch or count read-back failed");
+                return MORNA_E_HIP;
+            }
+            return MORNA_OK;
+        };
+
         for (int attempt = 0; attempt < 3 && !pending.empty(); attempt++) {
-            attempts_run++;
             const int32_t n_chunks = make_tasks(pending, attempt, tasks);
             const int32_t A = (int32_t)tasks.size();
             int64_t rows = 0;
@@ -1052,16 +1110,15 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
 #define TMW_LAUNCH(NVV)                                                                                              \
     hipLaunchKernelGGL(two_means_wave_kernel<NVV>, dim3(wg), dim3(256), 0, h->stream, h->X.p, h->rowinfo.p, N, dpad, \
                        h->perm.p, d_tasks.p, A, seed, hp_level)
-                // Four waves per node while the level's nodes fit the chip at once (2 workgroups per CU): the
-                // node's 200-step chain is then ~1.6x shorter (C3: 0.45 / 0.62 ms instead of 0.73 / 0.75 ms at
-                // the two shallowest levels).  Deeper levels are bound by VALU throughput, not by the chain, and
-                // four waves only add redundant work there (C3, 1600 nodes: 2.0 ms instead of 1.2 ms).
-                // MORNA_TM_QUAD=0: one wave per node everywhere.
-                static const bool tm_quad_on = !(getenv("MORNA_TM_QUAD") && atoi(getenv("MORNA_TM_QUAD")) == 0);
-                const bool tm_quad = tm_quad_on && A <= 2 * h->n_cus;
+                // Four waves per node (strips) while the level's nodes fit the chip at once (2 workgroups per CU): the
+                // node's 200-step chain is then 2-3x shorter (C3: 0.32 / 0.28 ms instead of 0.7 ms at the two
+                // shallowest levels).  Deeper levels are bound by the HBM gather of the rows (C3, 1600 nodes: 5.9 TB/s)
+                // and four waves per node only add work there.  MORNA_TM_STRIP=0: one wave per node everywhere.
+                static const bool tm_strip_on = !(getenv("MORNA_TM_STRIP") && atoi(getenv("MORNA_TM_STRIP")) == 0);
+                const bool tm_quad = tm_strip_on && A <= 2 * h->n_cus;
 #define TMQ_LAUNCH(NVV)                                                                                                 \
-    hipLaunchKernelGGL((two_means_quad_kernel<NVV, 4>), dim3((unsigned)A), dim3(256), 0, h->stream, h->X.p, h->rowinfo.p, \
-                       N, dpad, h->perm.p, d_tasks.p, seed, hp_level)
+    hipLaunchKernelGGL((two_means_strip_kernel<NVV, TM_STRIP_DEPTH>), dim3((unsigned)A), dim3(256), 0, h->stream, h->X.p, \
+                       h->rowinfo.p, N, dpad, h->perm.p, d_tasks.p, seed, hp_level)
                 if (tm_quad && nvq == 12) TMQ_LAUNCH(12);
                 else if (tm_quad && nvq == 8) TMQ_LAUNCH(8);
                 else if (tm_quad && nvq == 4) TMQ_LAUNCH(4);
@@ -1135,9 +1192,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                                    h->perm.p, d_tasks.p, d_sched.p, n_chunks, seed, hp_level, side.p, d_ones.p);
             }
             F_TRY(hipGetLastError());
-            h_ones.resize((size_t)A);
-            F_TRY(hipMemcpyAsync(h_ones.data(), d_ones.p, (size_t)A * 4, hipMemcpyDeviceToHost, h->stream));
-            F_TRY(hipStreamSynchronize(h->stream));
+            if ((rc = partition_and_fetch_counts(A, rows))) { cleanup(); return rc; }
             h->stats.split_attempts += A;
             h->stats.split_rows += rows;
             std::vector<int32_t> still;
@@ -1145,11 +1200,10 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 const int32_t i = pending[(size_t)a];
                 final_ones[(size_t)i] = h_ones[(size_t)a];
                 const int64_t n1 = h_ones[(size_t)a], n0 = tasks[(size_t)a].count - n1;
-                if (!(split_imbalance(n0, n1) < 0.95)) still.push_back(i);
+                if (!(split_imbalance(n0, n1) < 0.95)) still.push_back(i);   // attempts 0, 1: sides_stand(); 2: sorted out below
             }
             pending.swap(still);
         }
-        const bool level_clean = attempts_run == 1 && pending.empty();   // one attempt, every node accepted
         // "If we didn't find a hyperplane, just randomize sides as a last option"
         std::vector<int32_t> fb;
         for (int32_t i : pending) {
@@ -1163,40 +1217,12 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             hipLaunchKernelGGL(fallback_kernel, dim3((unsigned)A), dim3(256), 0, h->stream, d_tasks.p, N, dpad, seed,
                                side.p, d_ones.p, hp_level);
             F_TRY(hipGetLastError());
-            h_ones.resize((size_t)A);
-            F_TRY(hipMemcpyAsync(h_ones.data(), d_ones.p, (size_t)A * 4, hipMemcpyDeviceToHost, h->stream));
-            F_TRY(hipStreamSynchronize(h->stream));
+            int64_t fb_rows = 0;
+            for (const SplitTask &t : tasks) fb_rows += t.count;
+            if ((rc = partition_and_fetch_counts(A, fb_rows))) { cleanup(); return rc; }
             for (int32_t a = 0; a < A; a++) final_ones[(size_t)fb[(size_t)a]] = h_ones[(size_t)a];
             h->stats.fallback_nodes += A;
         }
-        // partition every split node of the level
-        {
-            std::vector<int32_t> all((size_t)S);
-            for (int32_t i = 0; i < S; i++) all[(size_t)i] = i;
-            // The host does not wait for the partition: the next level's tasks follow from the counts it already
-            // has, and everything it enqueues is ordered behind the partition on the stream.  The host copies of
-            // this launch's arguments are therefore kept (not reused) until the build's final synchronisation.
-            kept_tasks.emplace_back();
-            kept_ones.push_back(final_ones);
-            make_tasks(all, 0, kept_tasks.back());
-            // when every node was accepted at its first attempt, the tasks and counts of that attempt are still
-            // in d_tasks / d_ones: nothing to send
-            if (!level_clean) {
-                F_TRY(hipMemcpyAsync(d_tasks.p, kept_tasks.back().data(), (size_t)S * sizeof(SplitTask), hipMemcpyHostToDevice, h->stream));
-                F_TRY(hipMemcpyAsync(d_ones.p, kept_ones.back().data(), (size_t)S * 4, hipMemcpyHostToDevice, h->stream));
-            }
-            ScopedTimer tm(h, MORNA_T_PARTITION, 0);
-            int64_t level_rows = 0;
-            for (const SplitTask &t : kept_tasks.back()) level_rows += t.count;
-            if (level_rows >= (int64_t)S * 2048)
-                hipLaunchKernelGGL(partition_kernel<1024>, dim3((unsigned)S), dim3(1024), 0, h->stream, d_tasks.p, N, side.p,
-                                   d_ones.p, h->perm.p, tmp.p);
-            else
-                hipLaunchKernelGGL(partition_kernel<256>, dim3((unsigned)S), dim3(256), 0, h->stream, d_tasks.p, N, side.p,
-                                   d_ones.p, h->perm.p, tmp.p);
-        }
-        F_TRY(hipGetLastError());
-
         // children: ids base + 2*i + side for the i-th split node of the level
         nxt.clear();
         for (int32_t i = 0; i < S; i++) {

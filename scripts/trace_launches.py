@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Print per-launch durations of the forest and query kernels from a rocprofv3 kernel trace csv (last step only)."""
+"""Print per-launch durations of the forest and query kernels from a rocprofv3 kernel trace csv (last step only);
+with --timeline after the file name: every launch of the last step with the device idle time before it."""
 import csv
 import sys
 
@@ -15,6 +16,19 @@ def name_of(raw):
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+timeline = len(sys.argv) > 2 and sys.argv[2] == "--timeline"
+if timeline:
+    # every launch of the last step, with the idle time of the device before it (start - latest end so far)
+    first = [i for i, r in enumerate(rows) if "hash_keys" in r["Kernel_Name"]][-1]
+    t0, busy_end, idle = int(rows[first]["Start_Timestamp"]), int(rows[first]["Start_Timestamp"]), 0
+    for r in rows[first:]:
+        a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        gap = max(a - busy_end, 0)
+        idle += gap
+        print("%9.3f ms  %-30s %8.3f ms   idle before %7.3f ms" % ((a - t0) / 1e6, name_of(r["Kernel_Name"])[:30], (b - a) / 1e6, gap / 1e6))
+        busy_end = max(busy_end, b)
+    print("step span %.3f ms, device idle %.3f ms" % ((busy_end - t0) / 1e6, idle / 1e6))
+    sys.exit(0)
 last_iota = max(i for i, r in enumerate(rows) if "iota_perm" in r["Kernel_Name"])
 for r in rows[last_iota:]:
     n = name_of(r["Kernel_Name"])

@@ -219,8 +219,9 @@ print("DIGEST", h.hexdigest(), a.forest_stats()["n_split"], a.forest_stats()["ma
 def test_filters_do_not_change_results(tmp_path):
     """The fp16 MFMA split filter + exact fallback (splitmm.hip) must write exactly the sides of the plain fp32
     kernels, and the fp16 candidate filter of the approximate search must return exactly what the all-fp32
-    search returns: the same seeded build and searches in three processes -- defaults, MORNA_SPLIT_MM=0
-    (row-window / chunk forms), MORNA_QUERY_FILTER=0 -- on rows spanning six orders of magnitude in norm, a zero
+    search returns; likewise the four-wave strip form of two_means and the one-wave form: the same seeded build
+    and searches in four processes -- defaults, MORNA_SPLIT_MM=0 (row-window / chunk forms), MORNA_QUERY_FILTER=0,
+    MORNA_TM_STRIP=0 -- on rows spanning six orders of magnitude in norm, a zero
     row, duplicates, near-duplicates in the 4th digit, exact scaled duplicates, a row of denormal scale and a row
     holding an infinity."""
     import os
@@ -231,11 +232,12 @@ def test_filters_do_not_change_results(tmp_path):
     with open(script, "w") as fh:
         fh.write(_FOREST_DIGEST.format(root=root))
     out = {}
-    for name, extra in (("default", {}), ("no_mm", {"MORNA_SPLIT_MM": "0"}), ("no_qf", {"MORNA_QUERY_FILTER": "0"})):
+    for name, extra in (("default", {}), ("no_mm", {"MORNA_SPLIT_MM": "0"}), ("no_qf", {"MORNA_QUERY_FILTER": "0"}),
+                        ("no_strip", {"MORNA_TM_STRIP": "0"})):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0].split()
         out[name] = line[1:]
-    assert out["default"] == out["no_mm"] == out["no_qf"], out
+    assert out["default"] == out["no_mm"] == out["no_qf"] == out["no_strip"], out
     assert int(out["default"][2]) >= 4                                      # deep enough for every form to run
