@@ -34,6 +34,11 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
+def dpad_of(d):
+    """row stride of the library: D rounded up to 256 floats"""
+    return (d + 255) // 256 * 256
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,8 +254,7 @@ def main():
     if rank == 0:
         # One roofline entry per kernel group, from the HIP-event timers of the library (events recorded on the
         # stream the kernels run on) and the algorithmic bytes of SURVEY.md 8(d) that the library counts per launch.
-        # The split group runs on the matrix cores: it is priced in flops (2 * D per row and split node of the
-        # fp32 formulation) against the dense fp16 MFMA peak; `executed_tflops` is what its contraction really does.
+        # The split group is priced at one pass over the rows per level (see below), not per (row, split node).
         kernels_of = {"features": ("morna::accumulate_kernel", "morna::transpose_convert_kernel", "morna::hash_keys_kernel",
                                    "morna::col_fill_kernel", "morna::line_flags_kernel", "morna::row_norms_kernel"),
                       "two_means": ("morna::two_means",), "split": ("morna::split_", "morna::rows_to_half", "morna::invert_kernel"),
@@ -275,11 +279,23 @@ def main():
                  "alg_bytes_per_launch": tm["bytes"] // launches, "ms_per_launch": tm["ms"] / launches,
                  "traffic": None}
             if name == "split":
+                # SURVEY.md 8(d) prices a split at 4*D bytes per (row, split node): one row read per dot, no reuse
+                # across trees (93 GB per level here: 24x what HBM can move in the time the level takes).  The
+                # level-synchronous forms reuse a row across the trees on chip, so the floor of a level is ONE
+                # pass over the rows of its split nodes (fp32, as stored) + its hyperplanes + one side byte per
+                # (row, tree); its arithmetic floor (2*D flop per row and split node on the fp16 matrix cores) is
+                # ~4x lower than that, so HBM is the roof that binds.  Both are reported.
+                levels = max(tm["launches"], 1)
+                rows_per_level = float(n_items)        # every row is in a split node of every tree at these levels
+                min_bytes = (4.0 * dpad_of(D) * rows_per_level + float(n_items) * T) * levels \
+                    + 4.0 * dpad_of(D) * st["n_split"] * args.steps
+                gbs = min_bytes / 1e9 / (tm["ms"] / 1e3)
                 flops = 2.0 * D * (st["split_rows"] + st["n_split"]) * args.steps      # one dot per row and split node
-                tf = flops / 1e12 / (tm["ms"] / 1e3)
                 executed = 2.0 * n_items * st["n_split"] * D * args.steps             # every row x every hyperplane of its level
-                g.update(bound="mfma", achieved=tf, peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / MFMA_F16_PEAK_TFLOPS,
-                         executed_tflops=executed / 1e12 / (tm["ms"] / 1e3))
+                g.update(achieved=gbs, frac=gbs / HBM_PEAK_GBS, alg_bytes_per_launch=int(min_bytes / levels),
+                         alg_bytes_per_launch_no_reuse=tm["bytes"] // launches,
+                         mfma_floor={"algorithmic_tflops": flops / 1e12 / (tm["ms"] / 1e3), "peak": MFMA_F16_PEAK_TFLOPS,
+                                     "executed_tflops": executed / 1e12 / (tm["ms"] / 1e3)})
             if tj:
                 ks = [v for k, v in tj["kernels"].items() if k.startswith(kernels_of[name])]
                 if ks:   # bytes past L2 per timed launch group, from separate rocprofv3 --pmc passes
@@ -291,7 +307,8 @@ def main():
         dominant = max(groups, key=lambda n: timers[n]["ms"])
         notes = {"two_means": "one chain of 200 dependent steps per split node (annoy's two_means): bound by the latency of "
                               "that chain at shallow levels and by VALU issue at deep ones; its rows are gathered at random",
-                 "split": "a level's sides as one fp16 MFMA contraction that filters + exact fp32 dots for the ~1% it leaves open",
+                 "split": "a level's sides as one fp16 MFMA contraction that filters + exact fp32 dots for the ~1% it leaves open; "
+                          "bytes = one pass over the fp32 rows per level + hyperplanes + side bytes (rows reused across trees on chip)",
                  "features": "fp64 accumulation in file order in LDS tiles; the nnz stream is read once per sample tile",
                  "query": "candidate rows gathered at random: fp16 filter pass, fp32 for the survivors"}
         roofline = dict(groups[dominant], note=notes[dominant])
