@@ -115,7 +115,9 @@ def _synthetic_lines(rng, n_samples, J, lo, hi, dup_keys=True, weird=True):
     return keys, np.array(rp, np.int64), np.array(s, np.int64), np.array(c, np.int64)
 
 
-@pytest.mark.parametrize("D,n_samples,J", [(64, 700, 1500), (3000, 2000, 3000), (257, 300, 50)])
+@pytest.mark.parametrize("D,n_samples,J", [(64, 700, 1500), (3000, 2000, 3000), (257, 300, 50),
+                                           (40, 70000, 4500)])   # > 65536 samples: the duplicate flags of the lines
+                                                                 # come from the workgroup-per-line kernel
 def test_features_synthetic_vs_oracle(capi, D, n_samples, J):
     rng = np.random.default_rng(8675309 + D)
     keys, rp, s, c = _synthetic_lines(rng, n_samples, J, 5, 120)
@@ -123,6 +125,7 @@ def test_features_synthetic_vs_oracle(capi, D, n_samples, J):
     ref = capi.index_features(buf, off, rp, s, c, n_samples, 20, D)
     a, prep = _gpu_features(keys, rp, s, c, n_samples, 20, D)
     assert prep["n_items"] == ref["n_items"]
+    assert n_samples < 65536 or prep["n_items"] > 65536
     assert prep["ext_ids"].tolist() == ref["ext_ids"].tolist()
     assert prep["skipped"] == ref["skipped"]
     assert a.get_items().tobytes() == ref["X"].tobytes()
