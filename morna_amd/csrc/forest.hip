@@ -64,9 +64,10 @@ __global__ __launch_bounds__(TM_THREADS) void two_means_kernel(const float *__re
                                                                const float *__restrict__ norm2, int64_t n_items,
                                                                int32_t dpad, const int32_t *__restrict__ perm,
                                                                const SplitTask *__restrict__ tasks, uint32_t seed,
-                                                               float *__restrict__ hp)
+                                                               float *__restrict__ hp, int32_t *__restrict__ ones)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (threadIdx.x == 0) ones[blockIdx.x] = 0;   // the split kernels that follow count this task's right side here
     float *p = (float *)smem;        // centroid p   [dpad]
     float *q = p + dpad;             // centroid q   [dpad]
     float *xs = q + dpad;            // current row  [dpad]
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256, 3) void two_means_wave_kernel(const float *__r
                                                              int64_t n_items, int32_t dpad,
                                                              const int32_t *__restrict__ perm,
                                                              const SplitTask *__restrict__ tasks, int32_t n_tasks,
-                                                             uint32_t seed, float *__restrict__ hp)
+                                                             uint32_t seed, float *__restrict__ hp, int32_t *__restrict__ ones)
 {
     __shared__ float4 xnext[256 / WAVE][NV * WAVE];   // per wave: the row of the coming step
     const int lane = threadIdx.x & (WAVE - 1);
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(256, 3) void two_means_wave_kernel(const float *__r
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     const int ti = blockIdx.x * (256 / WAVE) + wv;
     if (ti >= n_tasks) return;   // no barrier below: waves are independent
+    if (lane == 0) ones[ti] = 0;   // the split kernels that follow count this task's right side here
     const SplitTask t = tasks[ti];
     const int nvec = dpad / 4;
     const int32_t *items = perm + (int64_t)t.tree * n_items + t.start;
@@ -361,9 +363,10 @@ __global__ __launch_bounds__(256) void two_means_strip_kernel(const float *__res
                                                             int64_t n_items, int32_t dpad,
                                                             const int32_t *__restrict__ perm,
                                                             const SplitTask *__restrict__ tasks, uint32_t seed,
-                                                            float *__restrict__ hp)
+                                                            float *__restrict__ hp, int32_t *__restrict__ ones)
 {
     static_assert(NV % 4 == 0, "the update works on groups of four k-steps");
+    if (threadIdx.x == 0) ones[blockIdx.x] = 0;   // the split kernels that follow count this task's right side here
     static_assert(TM_ITERS % DEPTH == 0, "the step loop is unrolled DEPTH times");
     constexpr int NS = NV / 4;
     __shared__ float ex[2][3][WAVE];   // folded values of up to three dots per canonical lane, by exchange parity
@@ -1083,7 +1086,8 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             const bool use_mm = mm_on && attempt == 0 && max_per_tree >= 1 && max_per_tree <= 32 &&
                                 rows * 2 >= (int64_t)n_trees * N;
             F_TRY(hipMemcpyAsync(d_tasks.p, tasks.data(), (size_t)A * sizeof(SplitTask), hipMemcpyHostToDevice, h->stream));
-            F_TRY(hipMemsetAsync(d_ones.p, 0, (size_t)A * 4, h->stream));
+            // (d_ones is zeroed by the two_means kernel of the attempt, task by task: a hipMemsetAsync costs ~15 us of
+            // idle device around its few microseconds)
             bool side_work = false;
             if (use_mm || use_rw) {
                 // row -> (task, position) per tree, and, the first time, the fp16 image of the rows: both depend only on
@@ -1109,7 +1113,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 const unsigned wg = (unsigned)((A + 3) / 4);
 #define TMW_LAUNCH(NVV)                                                                                              \
     hipLaunchKernelGGL(two_means_wave_kernel<NVV>, dim3(wg), dim3(256), 0, h->stream, h->X.p, h->rowinfo.p, N, dpad, \
-                       h->perm.p, d_tasks.p, A, seed, hp_level)
+                       h->perm.p, d_tasks.p, A, seed, hp_level, d_ones.p)
                 // Four waves per node (strips) while the level's nodes fit the chip at once (2 workgroups per CU): the
                 // node's 200-step chain is then 2-3x shorter (C3: 0.32 / 0.28 ms instead of 0.7 ms at the two
                 // shallowest levels).  Deeper levels are bound by the HBM gather of the rows (C3, 1600 nodes: 5.9 TB/s)
@@ -1118,7 +1122,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 const bool tm_quad = tm_strip_on && A <= 2 * h->n_cus;
 #define TMQ_LAUNCH(NVV)                                                                                                 \
     hipLaunchKernelGGL((two_means_strip_kernel<NVV, TM_STRIP_DEPTH>), dim3((unsigned)A), dim3(256), 0, h->stream, h->X.p, \
-                       h->rowinfo.p, N, dpad, h->perm.p, d_tasks.p, seed, hp_level)
+                       h->rowinfo.p, N, dpad, h->perm.p, d_tasks.p, seed, hp_level, d_ones.p)
                 if (tm_quad && nvq == 12) TMQ_LAUNCH(12);
                 else if (tm_quad && nvq == 8) TMQ_LAUNCH(8);
                 else if (tm_quad && nvq == 4) TMQ_LAUNCH(4);
@@ -1131,7 +1135,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 else if (nvq == 12) TMW_LAUNCH(12);
                 else   // other row lengths (or too long for the register file): centroids in LDS, one workgroup per node
                     hipLaunchKernelGGL(two_means_kernel, dim3((unsigned)A), dim3(TM_THREADS), (size_t)dpad * 4 * 3, h->stream,
-                                       h->X.p, h->norm2.p, N, dpad, h->perm.p, d_tasks.p, seed, hp_level);
+                                       h->X.p, h->norm2.p, N, dpad, h->perm.p, d_tasks.p, seed, hp_level, d_ones.p);
 #undef TMW_LAUNCH
 #undef TMQ_LAUNCH
             }

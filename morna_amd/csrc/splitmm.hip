@@ -33,8 +33,10 @@ static inline float sm_eps(int32_t dpad) { return 1.02f * 0.0009765625f + 4.f * 
 // decided by the filter).
 __global__ __launch_bounds__(256) void rows_to_half_kernel(const float *__restrict__ src, int64_t rows, int32_t dpad,
                                                            _Float16 *__restrict__ dst, float *__restrict__ norm,
-                                                           float *__restrict__ inv_scale /* 2^-e per row, or null */)
+                                                           float *__restrict__ inv_scale /* 2^-e per row, or null */,
+                                                           unsigned int *__restrict__ zero_me /* a counter to reset, or null */)
 {
+    if (zero_me && blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0u;
     const int lane = threadIdx.x & (WAVE - 1);
     const int64_t r = (int64_t)blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
     if (r >= rows) return;
@@ -295,7 +297,7 @@ int split_mm_prepare_rows(morna_index *h, hipStream_t stream)
     MORNA_TRY(x16.alloc((size_t)h->n_items * h->dpad));
     MORNA_TRY(xn.alloc((size_t)h->n_items * 2));
     hipLaunchKernelGGL(rows_to_half_kernel, dim3((unsigned)((h->n_items + 3) / 4)), dim3(256), 0, stream, h->X.p,
-                       h->n_items, h->dpad, x16.p, xn.p, xn.p + h->n_items);
+                       h->n_items, h->dpad, x16.p, xn.p, xn.p + h->n_items, (unsigned int *)nullptr);
     HIP_TRY(hipGetLastError());
     h->half_valid = true;
     return MORNA_OK;
@@ -318,9 +320,9 @@ int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, co
     MORNA_TRY(ambuf.alloc(16 + cap * sizeof(int2)));
     unsigned int *amb_count = (unsigned int *)ambuf.p;
     int2 *amb = (int2 *)(ambuf.p + 16);
-    HIP_TRY(hipMemsetAsync(amb_count, 0, 16, h->stream));
+    // the open-pair counter is reset by the kernel that converts the level's hyperplanes (same stream, just before)
     hipLaunchKernelGGL(rows_to_half_kernel, dim3((unsigned)((n_tasks + 3) / 4)), dim3(256), 0, h->stream, hp_level,
-                       (int64_t)n_tasks, h->dpad, h16.p, hn.p, (float *)nullptr);
+                       (int64_t)n_tasks, h->dpad, h16.p, hn.p, (float *)nullptr, amb_count);
     const unsigned n_rt = (unsigned)((N + SM_TILE - 1) / SM_TILE), n_ct = (unsigned)((n_tasks + SM_TILE - 1) / SM_TILE);
     const dim3 grid(8u * ((n_rt + 7) / 8) * n_ct);
     HIP_TRY(hipFuncSetAttribute((const void *)split_mm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_TILE * SM_TILE * 4));
