@@ -211,3 +211,21 @@ def test_pretokenised_cache_roundtrip_and_invalidation(tmp_path, embedded):
         got = mindex.ParsedLines(src, None, 6, cache=cache)
         assert not got.from_cache and got.n_items == 7
         assert open(cache, "rb").read() == blob
+
+
+def test_division_by_count_route_quick(tmp_path):
+    """The fp32 FMA route two_means uses for t / (n + 1) (devutil.hpp centroid_step4) against the division, on the
+    host: every float significand of t at three exponents and all subnormals (one in seven), seven divisors.
+    `scripts/check_intdiv_route.c` without an argument runs all 201 divisors and eleven exponents (minutes)."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "check_intdiv")
+    subprocess.run(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", os.path.join(root, "scripts", "check_intdiv_route.c"),
+                    "-o", exe, "-lm"], check=True)
+    r = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 differ" in r.stdout.splitlines()[0]
