@@ -167,6 +167,7 @@ static int ensure_host_rows(morna_index *h, int64_t n)
     if (h->host_n == 0 && h->n_items > 0 && !h->host_dirty) {
         // items live only in HBM (feature build / load): bring them back before mixing
         h->host_rows.assign((size_t)h->n_items * h->dim, 0.f);
+        MORNA_TRY(settle(h));
         HIP_TRY(hipMemcpy2D(h->host_rows.data(), (size_t)h->dim * 4, h->X.p, (size_t)h->dpad * 4, (size_t)h->dim * 4,
                             (size_t)h->n_items, hipMemcpyDeviceToHost));
         h->host_n = h->n_items;
@@ -181,6 +182,7 @@ static int ensure_host_rows(morna_index *h, int64_t n)
 int morna_add_item(morna_index *h, int32_t id, const double *v)
 {
     CHECK_H(h);
+    MORNA_TRY(settle(h));
     if (id < 0 || !v) {
         set_error("add_item: item id must be non-negative");
         return MORNA_E_RANGE;
@@ -200,6 +202,7 @@ int morna_add_item(morna_index *h, int32_t id, const double *v)
 int morna_add_items_f32(morna_index *h, int32_t first_id, const float *rows, int64_t n)
 {
     CHECK_H(h);
+    MORNA_TRY(settle(h));
     if (first_id < 0 || n < 0 || (n > 0 && !rows)) {
         set_error("add_items: bad arguments");
         return MORNA_E_INVALID;
@@ -219,6 +222,7 @@ int morna_stage_junctions(morna_index *h, const uint8_t *key_bytes, const int64_
                           const int64_t *row_ptr, const int32_t *item_ids, const int32_t *cov, const double *idf)
 {
     CHECK_H(h);
+    MORNA_TRY(settle(h));
     if (J < 0 || (J > 0 && (!key_bytes || !key_off || !row_ptr || !item_ids || !cov || !idf))) {
         set_error("stage_junctions: null input");
         return MORNA_E_INVALID;
@@ -259,6 +263,7 @@ int morna_stage_junctions(morna_index *h, const uint8_t *key_bytes, const int64_
 int morna_unstage_junctions(morna_index *h)
 {
     CHECK_H(h);
+    MORNA_TRY(settle(h));
     h->s_keys.release(); h->s_key_off.release(); h->s_row_ptr.release();
     h->s_ids.release(); h->s_cov.release(); h->s_idf.release();
     for (int i = 0; i < 8; i++) h->scratch[i].release();   // feature-build scratch (fp64 column image ...)
@@ -278,6 +283,7 @@ int morna_hash_keys(morna_index *h, const uint8_t *key_bytes, const int64_t *key
                     int32_t *col_out, int32_t *sign_out)
 {
     CHECK_H(h);
+    MORNA_TRY(settle(h));
     HIP_TRY(hipSetDevice(h->device));
     return hash_keys_device(h, key_bytes, key_off, J, hash_out, col_out, sign_out);
 }
@@ -297,6 +303,7 @@ int morna_get_item_vector(morna_index *h, int32_t id, float *out)
         set_error("Item index %d out of range [0, %lld)", id, (long long)h->n_items);
         return MORNA_E_RANGE;
     }
+    MORNA_TRY(settle(h));
     HIP_TRY(hipMemcpy(out, h->X.p + (size_t)id * h->dpad, (size_t)h->dim * 4, hipMemcpyDeviceToHost));
     return MORNA_OK;
 }
@@ -331,6 +338,7 @@ int morna_get_items(morna_index *h, float *rows_out)
     CHECK_H(h);
     HIP_TRY(hipSetDevice(h->device));
     MORNA_TRY(upload_host_rows(h));
+    MORNA_TRY(settle(h));
     if (h->n_items > 0)
         HIP_TRY(hipMemcpy2D(rows_out, (size_t)h->dim * 4, h->X.p, (size_t)h->dpad * 4, (size_t)h->dim * 4,
                             (size_t)h->n_items, hipMemcpyDeviceToHost));
@@ -342,6 +350,7 @@ int morna_get_norms2(morna_index *h, float *out)
     CHECK_H(h);
     HIP_TRY(hipSetDevice(h->device));
     MORNA_TRY(upload_host_rows(h));
+    MORNA_TRY(settle(h));
     if (h->n_items > 0) HIP_TRY(hipMemcpy(out, h->norm2.p, (size_t)h->n_items * 4, hipMemcpyDeviceToHost));
     return MORNA_OK;
 }
@@ -472,6 +481,7 @@ int morna_save(morna_index *h, const char *path)
     hd.stats = h->stats;
     bool ok = fwrite(&hd, sizeof(hd), 1, f) == 1;
     std::vector<float> buf;
+    if (settle(h) != MORNA_OK) ok = false;
     if (ok && h->n_items > 0) {
         buf.resize((size_t)h->n_items * h->dim);
         if (hipMemcpy2D(buf.data(), (size_t)h->dim * 4, h->X.p, (size_t)h->dpad * 4, (size_t)h->dim * 4,
@@ -503,6 +513,7 @@ int morna_save(morna_index *h, const char *path)
 int morna_load(morna_index *h, const char *path)
 {
     CHECK_H(h);
+    MORNA_TRY(settle(h));
     HIP_TRY(hipSetDevice(h->device));
     FILE *f = fopen(path, "rb");
     if (!f) {
@@ -661,6 +672,7 @@ int morna_merge_topk(const int64_t *ids, const float *dist, int32_t world, int64
 int morna_synchronize(morna_index *h)
 {
     CHECK_H(h);
+    MORNA_TRY(settle(h));
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return MORNA_OK;

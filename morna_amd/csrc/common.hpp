@@ -133,6 +133,7 @@ struct morna_index {
     morna::DevBuf<float> norm2;  // [n_items] canonical dot(x, x)
     morna::DevBuf<morna::RowInfo> rowinfo;   // [n_items] norm2 again with what two_means derives from it
     bool norms_valid = false;
+    bool unsettled = false;      // build_features() returned without waiting for its kernels: blocking copies must settle() first
     bool half_valid = false;     // scratch[19] / [20] hold the fp16 image of X, its norms and scales (splitmm.hip)
 
     // staged junction lines (CSR by line, file order)
@@ -197,6 +198,21 @@ struct ScopedTimer {
         h->pending_ev.push_back(pe);
     }
 };
+
+// Before a blocking copy (which is not ordered against the handle's non-blocking stream) reads what the feature
+// build wrote: wait for the stream once.
+inline int settle(morna_index *h)
+{
+    if (h->unsettled) {
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) {
+            set_error("hipStreamSynchronize failed: %s", hipGetErrorString(e));
+            return MORNA_E_HIP;
+        }
+        h->unsettled = false;
+    }
+    return MORNA_OK;
+}
 
 // implemented in features.hip / forest.hip / knn.hip
 int upload_host_rows(morna_index *h);

@@ -554,7 +554,10 @@ int build_features(morna_index *h, int64_t n_items)
         h->built = false;
         MORNA_TRY(compute_norms(h));
     }
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    // No synchronisation here: everything above is ordered on the handle's stream and reads no caller memory, and
+    // whatever the caller does next with the handle (build, queries, get_items) is ordered behind it or synchronises
+    // itself -- a forest build that follows starts without the device draining first.  Blocking copies settle() first.
+    h->unsettled = true;
     return MORNA_OK;
 }
 
