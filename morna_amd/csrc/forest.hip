@@ -1126,6 +1126,11 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 if (tm_quad && nvq == 12) TMQ_LAUNCH(12);
                 else if (tm_quad && nvq == 8) TMQ_LAUNCH(8);
                 else if (tm_quad && nvq == 4) TMQ_LAUNCH(4);
+                else if (tm_quad && nvq == 16) TMQ_LAUNCH(16);   // rows too long for the one-wave register form: strips
+                else if (tm_quad && nvq == 20) TMQ_LAUNCH(20);   // (8 float4 per lane and array at D = 8192) instead of the
+                else if (tm_quad && nvq == 24) TMQ_LAUNCH(24);   // LDS form
+                else if (tm_quad && nvq == 28) TMQ_LAUNCH(28);
+                else if (tm_quad && nvq == 32) TMQ_LAUNCH(32);
                 else if (nvq == 1) TMW_LAUNCH(1);
                 else if (nvq == 2) TMW_LAUNCH(2);
                 else if (nvq == 3) TMW_LAUNCH(3);
