@@ -17,7 +17,7 @@
 //                        never share a cell and a line touches a cell at most
 //                        once (else it is replayed serially), so the per-cell
 //                        order is the file order, with no atomics.
-//   transpose_convert    fp64 [D][N] -> fp32 [N][dpad] through an LDS tile
+//   transpose_convert    fp32 [D][N] (each cell rounded once from its fp64 sum) -> fp32 [N][dpad] through an LDS tile
 //   row_norms_kernel     canonical dot(x, x) per row
 #include <algorithm>
 #include <cstring>
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(LFW_WAVES * WAVE) void line_flags_wave_kernel(const
 __global__ __launch_bounds__(ACC_THREADS) void accumulate_kernel(
     int32_t n_tiles, int32_t n_cols, const int32_t *__restrict__ col_off, const int32_t *__restrict__ col_lines, const double *__restrict__ sidf,
     const uint8_t *__restrict__ flags, const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ ids,
-    const int32_t *__restrict__ cov, int64_t n_items, double *__restrict__ colacc /* [D][n_items] */)
+    const int32_t *__restrict__ cov, int64_t n_items, float *__restrict__ colacc /* [D][n_items] */)
 {
     __shared__ double acc[ACC_TILE];
     __shared__ int64_t s_b[ACC_LINES], s_e[ACC_LINES];
@@ -314,14 +314,16 @@ __global__ __launch_bounds__(ACC_THREADS) void accumulate_kernel(
             }
         }
     }
-    double *out = colacc + (int64_t)c * n_items + r_lo;
-    for (int i = tid; i < (int)span; i += ACC_THREADS) out[i] = acc[i];
+    // the cell's fp64 sum is complete: the one rounding to fp32 (add_item's cast, morna.py:405-424) happens here, and
+    // the column image that transpose_kernel turns into rows is fp32 (half the bytes written and read again)
+    float *out = colacc + (int64_t)c * n_items + r_lo;
+    for (int i = tid; i < (int)span; i += ACC_THREADS) out[i] = __double2float_rn(acc[i]);
 }
 
-// --------------------------------------------------- fp64 [D][N] -> fp32 [N][dpad]
+// --------------------------------------------------- fp32 [D][N] -> fp32 [N][dpad]
 
 #define TT 64
-__global__ __launch_bounds__(256) void transpose_convert_kernel(const double *__restrict__ colacc,
+__global__ __launch_bounds__(256) void transpose_convert_kernel(const float *__restrict__ colacc,
                                                                 int64_t n_items, int32_t dim, int32_t dpad,
                                                                 float *__restrict__ X)
 {
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(256) void transpose_convert_kernel(const double *__
         int32_t c = c0 + r;
         int64_t n = n0 + tx;
         float v = 0.f;
-        if (c < dim && n < n_items) v = __double2float_rn(colacc[(int64_t)c * n_items + n]);  // add_item cast
+        if (c < dim && n < n_items) v = colacc[(int64_t)c * n_items + n];   // already rounded to fp32 by accumulate_kernel
         tile[r][tx] = v;
     }
     __syncthreads();
@@ -479,7 +481,8 @@ int build_features(morna_index *h, int64_t n_items)
     }
     // scratch lives in the handle (released by morna_unstage_junctions): a rebuild does no hipMalloc
     ScratchRef<int32_t> col(h->scratch[0]), col_count(h->scratch[1]), col_off(h->scratch[2]), col_lines(h->scratch[3]);
-    ScratchRef<double> sidf(h->scratch[4]), colacc(h->scratch[5]);
+    ScratchRef<double> sidf(h->scratch[4]);
+    ScratchRef<float> colacc(h->scratch[5]);
     ScratchRef<uint8_t> flags(h->scratch[6]);
     ScratchRef<int32_t> bucket_aux(h->scratch[7]);   // [J] rank of a line in its chunk, then [n_chunks][D] chunk counts / bases
     // algorithmic bytes of this pass: 8*nnz + keys + 8*J + 4*N*D
