@@ -9,11 +9,14 @@
 // traffic).
 //
 // The product is taken on fp16 COPIES of the rows and hyperplanes (each scaled by a power of two so
-// that its largest element lies in [2^14, 2^15)), and it only FILTERS: with y = fp16(s x), g = fp16(t h),
-//   |sum y_i g_i (as computed) - s t dot(x, h)|  <=  EPS * |y| * |g|,
-//   EPS = 2^-10 (two roundings to 11 bits) + 4 * dpad * 2^-24 (fp32 accumulation of dpad products in any
-//         order, with room for adders that truncate) + the rounding of the canonical fp32 dot itself (< 4e-6),
-// so whenever |C| > EPS |y| |g| the sign of C IS the sign of the canonical wave_dot the split is defined
+// that its largest element lies in [2^14, 2^15)), and it only FILTERS.  With y = fp16(s x) = s x - d and
+// g = fp16(t h) = t h - f (d, f: the rounding errors, whose Euclidean norms are MEASURED when the copies are made:
+// about 2^-11 / sqrt(3) of |y|, not the worst case 2^-11),
+//   |sum y_i g_i (as computed) - s t dot(x, h)|  <=  (EACC |y| + |d|) |g| + (|y| + |d|) |f|,
+//   EACC = 2 * dpad * 2^-24 (fp32 accumulation in any order, with room for adders that truncate or align to the
+//          largest addend: the even and the odd K-steps go to two accumulators of dpad / 2 products each,
+//          4 * 2^-24 per product, added once at the end) + the rounding of the canonical fp32 dot itself (< 4e-6),
+// so whenever |C| exceeds that bound the sign of C IS the sign of the canonical wave_dot the split is defined
 // by.  The (row, node) pairs the filter cannot decide -- about 1 % -- are listed and recomputed by
 // split_amb_kernel with wave_dot on the fp32 data, including the dot == 0 coin flip.  The sides written
 // are therefore exactly those of split_kernel; the forest stays bit-identical to the oracle.
@@ -25,7 +28,7 @@ namespace morna {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static inline float sm_eps(int32_t dpad) { return 1.02f * 0.0009765625f + 4.f * (float)dpad * 5.9604645e-8f + 4e-6f; }
+static inline float sm_eps(int32_t dpad) { return (2.f * (float)dpad + 2.f) * 5.9604645e-8f + 4.1e-6f; }   // EACC
 
 // ---- fp16 image of a row-major fp32 matrix: one wave per row ---------------------------------------
 // dst row = fp16(2^e * src row) with max |2^e x_i| in [2^14, 2^15); norm[row] = an upper bound of the
@@ -33,6 +36,7 @@ static inline float sm_eps(int32_t dpad) { return 1.02f * 0.0009765625f + 4.f * 
 // decided by the filter).
 __global__ __launch_bounds__(256) void rows_to_half_kernel(const float *__restrict__ src, int64_t rows, int32_t dpad,
                                                            _Float16 *__restrict__ dst, float *__restrict__ norm,
+                                                           float *__restrict__ err /* |s x - y| per row (upper bound) */,
                                                            float *__restrict__ inv_scale /* 2^-e per row, or null */,
                                                            unsigned int *__restrict__ zero_me /* a counter to reset, or null */)
 {
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(256) void rows_to_half_kernel(const float *__restri
     if (m > 0.f) e = 14 - ilogbf(m);
     if (e > 126 || e < -126) bad = true;   // the scale itself must be a normal float
     const float s = bad ? 0.f : ldexpf(1.f, e);
-    float sum = 0.f;
+    float sum = 0.f, sume = 0.f;
     _Float16 *d = dst + r * dpad;
     for (int i = lane; i < nvec; i += WAVE) {
         const float4 v = x[i];
@@ -66,11 +70,16 @@ __global__ __launch_bounds__(256) void rows_to_half_kernel(const float *__restri
         *(f16x4 *)(d + 4 * i) = (f16x4){h0, h1, h2, h3};
         const float f0 = (float)h0, f1 = (float)h1, f2 = (float)h2, f3 = (float)h3;
         sum += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+        // the rounding error of each element, exactly: s x_i is exact (power of two), y_i has 11 bits of it
+        const float e0 = v.x * s - f0, e1 = v.y * s - f1, e2 = v.z * s - f2, e3 = v.w * s - f3;
+        sume += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
     }
     sum = wave_sum_xor(sum);
+    sume = wave_sum_xor(sume);
     // fp32 sum of <= 8192 squares: relative error < 1e-3; the bound is widened by that much
     if (lane == 0) {
         norm[r] = bad ? INFINITY : sqrtf(sum) * 1.002f;
+        err[r] = bad ? 0.f : sqrtf(sume) * 1.002f + 1e-30f;   // (elements of s x below the fp32 normal range: < 1e-38 each)
         if (inv_scale) inv_scale[r] = bad ? 0.f : ldexpf(1.f, -e);
     }
 }
@@ -82,8 +91,8 @@ __global__ __launch_bounds__(256) void rows_to_half_kernel(const float *__restri
 #define SM_OPEN 1536             // open pairs a tile keeps in LDS (12 KB; ~500 expected of 16384 at the root level)
 
 __global__ __launch_bounds__(SM_THREADS) void split_mm_kernel(
-    const _Float16 *__restrict__ X16, const float *__restrict__ xn, int64_t n_items, int32_t dpad,
-    const _Float16 *__restrict__ H16, const float *__restrict__ hn, int32_t n_tasks,
+    const _Float16 *__restrict__ X16, const float *__restrict__ xn, const float *__restrict__ xe, int64_t n_items, int32_t dpad,
+    const _Float16 *__restrict__ H16, const float *__restrict__ hn, const float *__restrict__ he, int32_t n_tasks,
     const SplitTask *__restrict__ tasks, const int32_t *__restrict__ row_task, const int32_t *__restrict__ row_pos,
     float eps, uint8_t *__restrict__ side, int32_t *__restrict__ ones, unsigned int *__restrict__ amb_count,
     int2 *__restrict__ amb, unsigned int amb_cap)
@@ -93,7 +102,7 @@ __global__ __launch_bounds__(SM_THREADS) void split_mm_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *Cs = (float *)smem;                    // result      [128 hyperplanes][128 rows]
     __shared__ int s_ones[SM_TILE], s_tree[SM_TILE], s_start[SM_TILE];
-    __shared__ float s_hn[SM_TILE];
+    __shared__ float s_hn[SM_TILE], s_he[SM_TILE];
     __shared__ int2 s_open[SM_OPEN];   // pairs this tile's filter left open
     __shared__ int s_nopen;
     __shared__ unsigned int s_obase;
@@ -132,11 +141,11 @@ __global__ __launch_bounds__(SM_THREADS) void split_mm_kernel(
                                              (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
     };
-    f32x16 acc[2];
+    f32x16 acc[2], acc_odd[2];   // even / odd K-steps: two shorter accumulation chains (the bound above)
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[j][e] = 0.f;
+        for (int e = 0; e < 16; e++) acc[j][e] = acc_odd[j][e] = 0.f;
     if (tid < SM_TILE) {
         const int col = c0 + tid < n_tasks ? c0 + tid : n_tasks - 1;
         const SplitTask t = tasks[col];
@@ -145,6 +154,7 @@ __global__ __launch_bounds__(SM_THREADS) void split_mm_kernel(
         s_tree[tid] = t.tree;
         s_start[tid] = t.start;
         s_hn[tid] = hn[col];
+        s_he[tid] = he[col];
     }
 
     dma(0, 0);
@@ -152,7 +162,7 @@ __global__ __launch_bounds__(SM_THREADS) void split_mm_kernel(
     __syncthreads();
     const int lr = lane & 31, lh = lane >> 5;
     const int xrow = wm * 32 + lr, xsw = (xrow >> 1) & 7;
-    for (int k0 = 0, buf = 0; k0 < dpad; k0 += SM_BK, buf ^= 1) {
+    auto kstep = [&](int k0, int buf, f32x16(&ac)[2]) {
         if (k0 + SM_BK < dpad) dma(k0 + SM_BK, buf ^ 1);   // next slab lands in the other buffer under the MFMAs
         const unsigned char *xs = smem + buf * (2 * SM_TILE * SM_BK * 2);
         const unsigned char *hs = xs + SM_TILE * SM_BK * 2;
@@ -168,12 +178,19 @@ __global__ __launch_bounds__(SM_THREADS) void split_mm_kernel(
             for (int tn = 0; tn < 2; tn++) {
                 const int hrow = wn * 64 + tn * 32 + lr;
                 const f16x8 h8 = *(const f16x8 *)(hs + hrow * 128 + ((kc ^ ((hrow >> 1) & 7)) << 4));
-                acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8, x8, acc[tn], 0, 0, 0);
+                ac[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8, x8, ac[tn], 0, 0, 0);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the next slab is in LDS
         __syncthreads();
+    };
+    // dpad is a multiple of 256: an even number of K-steps; the buffer index is the step's parity
+    for (int k0 = 0; k0 < dpad; k0 += 2 * SM_BK) {
+        kstep(k0, 0, acc);
+        kstep(k0 + SM_BK, 1, acc_odd);
     }
+#pragma unroll
+    for (int tn = 0; tn < 2; tn++) acc[tn] = acc[tn] + acc_odd[tn];
 
     // The result goes to LDS as C[hyperplane][row].  C/D layout of the 32x32 MFMA: n = lane & 31 (a row of X),
     // m = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (a hyperplane = a task of the level).
@@ -190,7 +207,9 @@ __global__ __launch_bounds__(SM_THREADS) void split_mm_kernel(
     const int t_first = s_tree[0], t_last = s_tree[c_hi - 1 - c0];
     const int64_t row = r0 + (tid & (SM_TILE - 1));
     const bool row_ok = row < n_items;
-    const float xnr = eps * xn[row_ok ? row : 0];
+    // bound of a pair = (EACC |y| + |d|) |g| + (|y| + |d|) |f|, 0.5 % of slack for its own roundings
+    const float xn_r = xn[row_ok ? row : 0], xe_r = xe[row_ok ? row : 0];
+    const float xa = (eps * xn_r + xe_r) * 1.005f, xb = (xn_r + xe_r) * 1.005f;
     constexpr int EU = 8, TSTEP = SM_THREADS / SM_TILE;   // trees per batch and thread; trees between a thread's steps
     for (int tb = t_first + (tid >> 7); tb <= t_last; tb += EU * TSTEP) {
         // the look-ups of a batch are issued together: each one is a dependent chain of two loads
@@ -212,7 +231,7 @@ __global__ __launch_bounds__(SM_THREADS) void split_mm_kernel(
             const int cl = mine ? a[u] - c0 : 0;
             const float c = Cs[cl * SM_TILE + (tid & (SM_TILE - 1))];   // bank = row: no conflict whatever the nodes are
             // false for NaN and for rows / hyperplanes that could not be scaled (norm = +inf)
-            const bool decided = mine && fabsf(c) > xnr * s_hn[cl];
+            const bool decided = mine && fabsf(c) > xa * s_hn[cl] + xb * s_he[cl];
             const bool one = decided && c > 0.f;
             if (decided) side[(int64_t)tr * n_items + s_start[cl] + pos[u]] = (uint8_t)one;
             // right-side counts: one LDS atomic per wave when its rows share the node (the rule at shallow levels)
@@ -293,11 +312,11 @@ int split_mm_prepare_rows(morna_index *h, hipStream_t stream)
 {
     if (h->half_valid) return MORNA_OK;
     ScratchRef<_Float16> x16(h->scratch[19]);
-    ScratchRef<float> xn(h->scratch[20]);   // [0, N): norms; [N, 2N): 2^-e per row (the query filter unscales with it)
+    ScratchRef<float> xn(h->scratch[20]);   // [0, N): norms; [N, 2N): 2^-e per row (the query filter unscales with it); [2N, 3N): |s x - y|
     MORNA_TRY(x16.alloc((size_t)h->n_items * h->dpad));
-    MORNA_TRY(xn.alloc((size_t)h->n_items * 2));
+    MORNA_TRY(xn.alloc((size_t)h->n_items * 3));
     hipLaunchKernelGGL(rows_to_half_kernel, dim3((unsigned)((h->n_items + 3) / 4)), dim3(256), 0, stream, h->X.p,
-                       h->n_items, h->dpad, x16.p, xn.p, xn.p + h->n_items, (unsigned int *)nullptr);
+                       h->n_items, h->dpad, x16.p, xn.p, xn.p + 2 * h->n_items, xn.p + h->n_items, (unsigned int *)nullptr);
     HIP_TRY(hipGetLastError());
     h->half_valid = true;
     return MORNA_OK;
@@ -316,17 +335,17 @@ int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, co
         return MORNA_E_INVALID;
     }
     MORNA_TRY(h16.alloc((size_t)n_tasks * h->dpad));
-    MORNA_TRY(hn.alloc((size_t)n_tasks));
+    MORNA_TRY(hn.alloc((size_t)n_tasks * 2));   // norms, then rounding-error norms
     MORNA_TRY(ambuf.alloc(16 + cap * sizeof(int2)));
     unsigned int *amb_count = (unsigned int *)ambuf.p;
     int2 *amb = (int2 *)(ambuf.p + 16);
     // the open-pair counter is reset by the kernel that converts the level's hyperplanes (same stream, just before)
     hipLaunchKernelGGL(rows_to_half_kernel, dim3((unsigned)((n_tasks + 3) / 4)), dim3(256), 0, h->stream, hp_level,
-                       (int64_t)n_tasks, h->dpad, h16.p, hn.p, (float *)nullptr, amb_count);
+                       (int64_t)n_tasks, h->dpad, h16.p, hn.p, hn.p + n_tasks, (float *)nullptr, amb_count);
     const unsigned n_rt = (unsigned)((N + SM_TILE - 1) / SM_TILE), n_ct = (unsigned)((n_tasks + SM_TILE - 1) / SM_TILE);
     const dim3 grid(8u * ((n_rt + 7) / 8) * n_ct);
     HIP_TRY(hipFuncSetAttribute((const void *)split_mm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_TILE * SM_TILE * 4));
-    hipLaunchKernelGGL(split_mm_kernel, grid, dim3(SM_THREADS), SM_TILE * SM_TILE * 4, h->stream, x16.p, xn.p, N, h->dpad, h16.p, hn.p, n_tasks, d_tasks,
+    hipLaunchKernelGGL(split_mm_kernel, grid, dim3(SM_THREADS), SM_TILE * SM_TILE * 4, h->stream, x16.p, xn.p, xn.p + 2 * N, N, h->dpad, h16.p, hn.p, hn.p + n_tasks, n_tasks, d_tasks,
                        row_task, row_pos, sm_eps(h->dpad), side, ones, amb_count, amb, (unsigned int)cap);
     hipLaunchKernelGGL(split_amb_kernel, dim3((unsigned)(4 * h->n_cus)), dim3(256), 0, h->stream, h->X.p, N, h->dpad, d_tasks,
                        row_pos, seed, hp_level, amb_count, amb, (unsigned int)cap, side, ones);
