@@ -307,7 +307,7 @@ def main():
         dominant = max(groups, key=lambda n: timers[n]["ms"])
         notes = {"two_means": "one chain of 200 dependent steps per split node (annoy's two_means): bound by the latency of "
                               "that chain at shallow levels and by VALU issue at deep ones; its rows are gathered at random",
-                 "split": "a level's sides as one fp16 MFMA contraction that filters + exact fp32 dots for the ~1% it leaves open; "
+                 "split": "a level's sides as one fp16 MFMA contraction that filters + exact fp32 dots for the ~0.5% it leaves open; "
                           "bytes = one pass over the fp32 rows per level + hyperplanes + side bytes (rows reused across trees on chip)",
                  "features": "fp64 accumulation in file order in LDS tiles; the nnz stream is read once per sample tile",
                  "query": "candidate rows gathered at random: fp16 filter pass, fp32 for the survivors"}
