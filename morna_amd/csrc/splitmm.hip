@@ -12,12 +12,12 @@
 // that its largest element lies in [2^14, 2^15)), and it only FILTERS.  With y = fp16(s x) = s x - d and
 // g = fp16(t h) = t h - f (d, f: the rounding errors, whose Euclidean norms are MEASURED when the copies are made:
 // about 2^-11 / sqrt(3) of |y|, not the worst case 2^-11),
-//   |sum y_i g_i (as computed) - s t dot(x, h)|  <=  (EACC |y| + |d|) |g| + (|y| + |d|) |f|,
+//   |sum y_i g_i (as computed) - s t wave_dot(x, h)|  <=  (EACC |y| + |d|) |g| + (|y| + |d|) |f|,
 //   EACC = 2 * dpad * 2^-24 (fp32 accumulation in any order, with room for adders that truncate or align to the
 //          largest addend: the even and the odd K-steps go to two accumulators of dpad / 2 products each,
 //          4 * 2^-24 per product, added once at the end) + the rounding of the canonical fp32 dot itself (< 4e-6),
 // so whenever |C| exceeds that bound the sign of C IS the sign of the canonical wave_dot the split is defined
-// by.  The (row, node) pairs the filter cannot decide -- about 1 % -- are listed and recomputed by
+// by.  The (row, node) pairs the filter cannot decide -- about 0.5 % -- are listed and recomputed by
 // split_amb_kernel with wave_dot on the fp32 data, including the dot == 0 coin flip.  The sides written
 // are therefore exactly those of split_kernel; the forest stays bit-identical to the oracle.
 #include "common.hpp"
