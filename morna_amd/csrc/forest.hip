@@ -1143,18 +1143,18 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 // shallowest levels).  Deeper levels are bound by the HBM gather of the rows (C3, 1600 nodes: 5.9 TB/s)
                 // and four waves per node only add work there.  MORNA_TM_STRIP=0: one wave per node everywhere.
                 static const bool tm_strip_on = !(getenv("MORNA_TM_STRIP") && atoi(getenv("MORNA_TM_STRIP")) == 0);
-                const bool tm_quad = tm_strip_on && A <= 2 * h->n_cus;
-#define TMQ_LAUNCH(NVV)                                                                                                 \
+                const bool tm_strip = tm_strip_on && A <= 2 * h->n_cus;
+#define TMS_LAUNCH(NVV)                                                                                                 \
     hipLaunchKernelGGL((two_means_strip_kernel<NVV, TM_STRIP_DEPTH>), dim3((unsigned)A), dim3(256), 0, h->stream, h->X.p, \
                        h->rowinfo.p, N, dpad, h->perm.p, d_tasks.p, seed, hp_level, d_ones.p)
-                if (tm_quad && nvq == 12) TMQ_LAUNCH(12);
-                else if (tm_quad && nvq == 8) TMQ_LAUNCH(8);
-                else if (tm_quad && nvq == 4) TMQ_LAUNCH(4);
-                else if (tm_quad && nvq == 16) TMQ_LAUNCH(16);   // rows too long for the one-wave register form: strips
-                else if (tm_quad && nvq == 20) TMQ_LAUNCH(20);   // (8 float4 per lane and array at D = 8192) instead of the
-                else if (tm_quad && nvq == 24) TMQ_LAUNCH(24);   // LDS form
-                else if (tm_quad && nvq == 28) TMQ_LAUNCH(28);
-                else if (tm_quad && nvq == 32) TMQ_LAUNCH(32);
+                if (tm_strip && nvq == 12) TMS_LAUNCH(12);
+                else if (tm_strip && nvq == 8) TMS_LAUNCH(8);
+                else if (tm_strip && nvq == 4) TMS_LAUNCH(4);
+                else if (tm_strip && nvq == 16) TMS_LAUNCH(16);   // rows too long for the one-wave register form: strips
+                else if (tm_strip && nvq == 20) TMS_LAUNCH(20);   // (8 float4 per lane and array at D = 8192) instead of the
+                else if (tm_strip && nvq == 24) TMS_LAUNCH(24);   // LDS form
+                else if (tm_strip && nvq == 28) TMS_LAUNCH(28);
+                else if (tm_strip && nvq == 32) TMS_LAUNCH(32);
                 else if (nvq == 1) TMW_LAUNCH(1);
                 else if (nvq == 2) TMW_LAUNCH(2);
                 else if (nvq == 3) TMW_LAUNCH(3);
@@ -1166,7 +1166,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                     hipLaunchKernelGGL(two_means_kernel, dim3((unsigned)A), dim3(TM_THREADS), (size_t)dpad * 4 * 3, h->stream,
                                        h->X.p, h->norm2.p, N, dpad, h->perm.p, d_tasks.p, seed, hp_level, d_ones.p);
 #undef TMW_LAUNCH
-#undef TMQ_LAUNCH
+#undef TMS_LAUNCH
             }
             if (!use_mm && !use_rw) {
                 // chunk form: launch order = chunks sorted by first row id, one contiguous run per XCD
