@@ -64,6 +64,8 @@ int morna_add_items_f32(morna_index *h, int32_t first_id, const float *rows, int
  *                           (host libm, so that it is bit-identical to Python)
  * stage = host -> HBM copy only; build_features = the kernels (hash, signed
  * column, fp64 accumulation in file order, fp64 -> fp32, row norms).
+ * build_features returns once its kernels are enqueued on the handle's stream: what follows on the handle is
+ * ordered behind them (entry points that copy with the host wait first); morna_synchronize() waits explicitly.
  */
 int morna_stage_junctions(morna_index *h, const uint8_t *key_bytes, const int64_t *key_off, int64_t J,
                           const int64_t *row_ptr, const int32_t *item_ids, const int32_t *cov,
