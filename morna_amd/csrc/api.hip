@@ -510,33 +510,70 @@ int morna_save(morna_index *h, const char *path)
     return MORNA_OK;
 }
 
-int morna_load(morna_index *h, const char *path)
+// A file is data from outside: everything the kernels index with is checked here, so that a truncated or
+// damaged blob is MORNA_E_IO and never an out-of-bounds access on the device or an exception across the C ABI.
+// (The .freq.mor / .map.mor files beside it are Python pickles, as in the reference, morna.py:449-455, 545-549:
+// an index file set must come from a trusted source.)
+static bool forest_tables_ok(const FileHeader &hd, const std::vector<int32_t> &perm, const std::vector<int32_t> &rec,
+                             const std::vector<int32_t> &tree, const std::vector<int32_t> &hp)
 {
-    CHECK_H(h);
-    MORNA_TRY(settle(h));
-    HIP_TRY(hipSetDevice(h->device));
-    FILE *f = fopen(path, "rb");
-    if (!f) {
-        set_error("Unable to open %s", path);
-        return MORNA_E_IO;
+    const int64_t n = hd.n_nodes, N = hd.n_items, T = hd.n_trees;
+    std::vector<uint8_t> refs((size_t)n, 0), slot_used((size_t)std::max<int64_t>(hd.n_split, 1), 0);
+    for (int64_t i = 0; i < n; i++) {
+        const int32_t c0 = rec[(size_t)i * 4], c1 = rec[(size_t)i * 4 + 1], start = rec[(size_t)i * 4 + 2], count = rec[(size_t)i * 4 + 3];
+        if (tree[(size_t)i] < 0 || tree[(size_t)i] >= T) return false;
+        if (start < 0 || count < 0 || (int64_t)start + count > N) return false;
+        if (i < T && (tree[(size_t)i] != i || start != 0 || count != N)) return false;   // roots are nodes 0 .. T-1
+        if (c0 < 0 || c1 < 0) {
+            if (c0 != -1 || c1 != -1 || hp[(size_t)i] != -1) return false;
+            continue;
+        }
+        // children come after their parent (breadth-first ids): no cycles; each node has exactly one parent
+        if (c0 <= i || c1 <= i || c0 >= n || c1 >= n || c0 == c1) return false;
+        if (refs[(size_t)c0]++ || refs[(size_t)c1]++) return false;
+        if (tree[(size_t)c0] != tree[(size_t)i] || tree[(size_t)c1] != tree[(size_t)i]) return false;
+        if (hp[(size_t)i] < 0 || hp[(size_t)i] >= hd.n_split || slot_used[(size_t)hp[(size_t)i]]++) return false;
     }
+    for (int64_t i = 0; i < n; i++)
+        if ((i < T) != (refs[(size_t)i] == 0)) return false;
+    for (int32_t v : perm)
+        if (v < 0 || v >= N) return false;
+    return true;
+}
+
+static int load_impl(morna_index *h, const char *path, FILE *f)
+{
     FileHeader hd;
     if (fread(&hd, sizeof(hd), 1, f) != 1 || memcmp(hd.magic, MAGIC, 8) != 0) {
-        fclose(f);
         set_error("%s is not a morna-hip index file", path);
         return MORNA_E_IO;
     }
     if (hd.dim != h->dim) {
-        fclose(f);
         set_error("Index size is not a multiple of vector size: file has dimension %d, index was created with %d", hd.dim, h->dim);
         return MORNA_E_IO;
     }
-    int rc = MORNA_OK;
+    // the header against itself and against the size of the file
+    const bool built = hd.built != 0;
+    bool sane = hd.n_items >= 0 && hd.n_items < INT32_MAX && hd.n_trees >= 0 && hd.n_trees <= (1 << 24) && hd.n_nodes >= 0 &&
+                hd.n_split >= 0 && hd.n_nodes < INT32_MAX;
+    if (sane && built) sane = hd.n_trees > 0 && hd.n_items > 0 && hd.n_nodes == (int64_t)hd.n_trees + 2 * hd.n_split;
+    if (sane && !built) sane = hd.n_nodes == 0 && hd.n_split == 0;
+    if (sane) {
+        long long expect = (long long)sizeof(hd) + 4ll * hd.n_items * hd.dim;
+        if (built) expect += 4ll * hd.n_trees * hd.n_items + 4ll * 6 * hd.n_nodes + 4ll * hd.n_split * hd.dim;
+        const long at = ftell(f);
+        sane = fseek(f, 0, SEEK_END) == 0 && (long long)ftell(f) == expect && fseek(f, at, SEEK_SET) == 0;
+    }
+    if (!sane) {
+        set_error("%s is truncated or damaged (header and file size disagree)", path);
+        return MORNA_E_IO;
+    }
     bool ok = true;
     std::vector<float> buf;
     h->host_rows.clear(); h->host_n = 0; h->host_dirty = false; h->built = false;
+    h->half_valid = false;
     h->n_items = hd.n_items;
-    if ((rc = h->X.alloc((size_t)std::max<int64_t>(hd.n_items, 1) * h->dpad))) { fclose(f); return rc; }
+    MORNA_TRY(h->X.alloc((size_t)std::max<int64_t>(hd.n_items, 1) * h->dpad));
     (void)hipMemset(h->X.p, 0, (size_t)std::max<int64_t>(hd.n_items, 1) * h->dpad * 4);
     if (hd.n_items > 0) {
         buf.resize((size_t)hd.n_items * h->dim);
@@ -544,8 +581,8 @@ int morna_load(morna_index *h, const char *path)
         if (ok && hipMemcpy2D(h->X.p, (size_t)h->dpad * 4, buf.data(), (size_t)h->dim * 4, (size_t)h->dim * 4,
                               (size_t)hd.n_items, hipMemcpyHostToDevice) != hipSuccess) ok = false;
     }
-    if (ok && (rc = compute_norms(h))) { fclose(f); return rc; }
-    if (ok && hd.built) {
+    if (ok) MORNA_TRY(compute_norms(h));
+    if (ok && built) {
         h->n_trees = hd.n_trees; h->n_nodes = hd.n_nodes; h->n_split = hd.n_split; h->seed = hd.seed; h->stats = hd.stats;
         std::vector<int32_t> perm((size_t)hd.n_trees * hd.n_items);
         h->h_node_rec.resize((size_t)hd.n_nodes * 4);
@@ -555,13 +592,16 @@ int morna_load(morna_index *h, const char *path)
         ok = ok && fread(h->h_node_rec.data(), 4, h->h_node_rec.size(), f) == h->h_node_rec.size();
         ok = ok && fread(h->h_node_tree.data(), 4, h->h_node_tree.size(), f) == h->h_node_tree.size();
         ok = ok && fread(h->h_node_hp.data(), 4, h->h_node_hp.size(), f) == h->h_node_hp.size();
+        if (ok && !forest_tables_ok(hd, perm, h->h_node_rec, h->h_node_tree, h->h_node_hp)) {
+            set_error("%s is damaged: its forest tables are inconsistent", path);
+            return MORNA_E_IO;
+        }
         if (ok) {
-            if ((rc = h->perm.alloc(perm.size())) || (rc = h->node_rec.alloc(h->h_node_rec.size())) ||
-                (rc = h->node_tree.alloc(h->h_node_tree.size())) || (rc = h->node_hp.alloc(h->h_node_hp.size())) ||
-                (rc = h->hp.alloc((size_t)std::max<int64_t>(hd.n_split, 1) * h->dpad))) {
-                fclose(f);
-                return rc;
-            }
+            MORNA_TRY(h->perm.alloc(perm.size()));
+            MORNA_TRY(h->node_rec.alloc(h->h_node_rec.size()));
+            MORNA_TRY(h->node_tree.alloc(h->h_node_tree.size()));
+            MORNA_TRY(h->node_hp.alloc(h->h_node_hp.size()));
+            MORNA_TRY(h->hp.alloc((size_t)std::max<int64_t>(hd.n_split, 1) * h->dpad));
             ok = hipMemcpy(h->perm.p, perm.data(), perm.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
                  hipMemcpy(h->node_rec.p, h->h_node_rec.data(), h->h_node_rec.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
                  hipMemcpy(h->node_tree.p, h->h_node_tree.data(), h->h_node_tree.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
@@ -576,13 +616,38 @@ int morna_load(morna_index *h, const char *path)
         }
         if (ok) h->built = true;
     }
-    fclose(f);
     if (!ok) {
         set_error("Unable to read %s (truncated or HIP copy failed)", path);
         return MORNA_E_IO;
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     return MORNA_OK;
+}
+
+int morna_load(morna_index *h, const char *path)
+{
+    CHECK_H(h);
+    MORNA_TRY(settle(h));
+    HIP_TRY(hipSetDevice(h->device));
+    FILE *f = path ? fopen(path, "rb") : nullptr;
+    if (!f) {
+        set_error("Unable to open %s", path ? path : "(null)");
+        return MORNA_E_IO;
+    }
+    int rc;
+    try {
+        rc = load_impl(h, path, f);
+    } catch (const std::exception &e) {   // bad_alloc / length_error must not cross the C ABI
+        set_error("Unable to read %s: %s", path, e.what());
+        rc = MORNA_E_IO;
+    }
+    fclose(f);
+    if (rc != MORNA_OK) {   // a failed load leaves an empty, unbuilt index rather than half of one
+        h->built = false;
+        h->n_items = 0;
+        h->norms_valid = false;
+    }
+    return rc;
 }
 
 // ---- measurement -----------------------------------------------------------------

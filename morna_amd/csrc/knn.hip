@@ -496,10 +496,22 @@ __global__ __launch_bounds__(256) void exact_rerank_kernel(const float *__restri
         if (ppqq > 0.0) distance = __dsub_rn(2.0, __ddiv_rn(__dmul_rn(2.0, pq), __dsqrt_rn(ppqq)));
         cd[t] = __dsqrt_rn(distance);   // NaN where Python's math.sqrt raises
     }
+    // A NaN is a row for which Python's math.sqrt raises ValueError (negative radicand: the cosine rounded to more
+    // than 1, i.e. a row all but parallel to the query).  The reference evaluates EVERY row, so one such row anywhere
+    // fails the whole query; such a row has a scan distance of ~0 and is therefore always among the candidates.  The
+    // query's count is reported as -1 and the caller raises (MornaSearch.exact_search_nn).
+    __shared__ int s_nan;
+    if (tid == 0) s_nan = 0;
+    __syncthreads();
+    {
+        bool any_nan = false;
+        for (int t = tid; t < n; t += 256) any_nan |= cd[t] != cd[t];
+        if (any_nan) s_nan = 1;
+    }
     __syncthreads();
     // rank = number of candidates that bisect_left insertion leaves in front:
     // smaller distance, or equal distance and HIGHER id (inserted later, lands first).
-    // NaN distances (Python would have raised) go last, by ascending id.
+    // NaN distances go last, by ascending id (the lists are still filled in, for diagnosis).
     for (int t = tid; t < n; t += 256) {
         const double d = cd[t];
         const int32_t id = c[t];
@@ -523,7 +535,7 @@ __global__ __launch_bounds__(256) void exact_rerank_kernel(const float *__restri
         ids_out[qi * k + r] = -1;
         dist_out[qi * k + r] = INFINITY;
     }
-    if (tid == 0) count_out[qi] = kout;
+    if (tid == 0) count_out[qi] = s_nan ? -1 : kout;
 }
 
 // fp64 query -> fp32 image + its squared norm (selection pass only)
@@ -555,7 +567,7 @@ __global__ void exact_prep_kernel(const double *__restrict__ Qd, int64_t nq, int
 #define MM_LD (MM_BK + 4)   // padded LDS row (floats); 144-byte rows keep float4 accesses aligned
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256) void exact_scan_mfma_kernel(const float *__restrict__ X, const float *__restrict__ norm2,
+__global__ __launch_bounds__(256, 2) void exact_scan_mfma_kernel(const float *__restrict__ X, const float *__restrict__ norm2,
                                                               int64_t n_items, int32_t dpad,
                                                               const float *__restrict__ Qf, const float *__restrict__ qn2,
                                                               int64_t nq, float *__restrict__ approx)
@@ -585,13 +597,15 @@ __global__ __launch_bounds__(256) void exact_scan_mfma_kernel(const float *__res
             *(float4 *)(Bs + row * MM_LD + c4 * 4) = gb[it];
         }
     };
-    f32x16 acc[2][2];
+    // two accumulators per tile, taking the 8-column blocks of a K slab alternately: an accumulation chain is
+    // dpad / 2 products long, which is what exact_scan_eps() prices
+    f32x16 acc[2][2], acc_b[2][2];
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; e++) acc[i][j][e] = acc_b[i][j][e] = 0.f;
 
     fetch(0);
     stash();
@@ -613,16 +627,21 @@ __global__ __launch_bounds__(256) void exact_scan_mfma_kernel(const float *__res
             for (int tm = 0; tm < 2; tm++)
 #pragma unroll
                 for (int tn = 0; tn < 2; tn++) {
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].x, b4[tn].x, acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].y, b4[tn].y, acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].z, b4[tn].z, acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].w, b4[tn].w, acc[tm][tn], 0, 0, 0);
+                    f32x16 &c = (blk & 1) ? acc_b[tm][tn] : acc[tm][tn];
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].x, b4[tn].x, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].y, b4[tn].y, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].z, b4[tn].z, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].w, b4[tn].w, c, 0, 0, 0);
                 }
         }
         __syncthreads();
         if (more) stash();
         __syncthreads();
     }
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++) acc[tm][tn] = acc[tm][tn] + acc_b[tm][tn];
     // epilogue: C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
     // A (queries) indexes the rows of the tile, B (matrix rows) its columns: 32 lanes write 32 consecutive r.
 #pragma unroll
@@ -640,6 +659,22 @@ __global__ __launch_bounds__(256) void exact_scan_mfma_kernel(const float *__res
                 }
             }
         }
+}
+
+// How far the scan's 2 - 2 cos can be from the exact value, times two (the k-th smallest scan value that sets the
+// threshold and the candidate itself can both be off): every row within this of the threshold is kept, so no row
+// of the true top k is lost.  Unit roundoff u = 2^-24, errors relative to |x| |q| >= sum |x_i q_i|:
+//   dot, vector-ALU scan : a lane adds dpad / 64 products in turn, then the 6-stage butterfly
+//   dot, matrix-core scan: two chains of dpad / 2 products each (one rounding per product-accumulate; measured on
+//                          MI355X by scripts/mfma_accum_probe.hip, profiles/r02_mfma_accum_probe.txt) and their sum
+//   norms (norm2 of the row, qn2 of the query): sums of dpad / 64 squares per lane + butterfly; half of each enters cos
+//   the fp32 image of the query and the rounding of the value itself: 2 u
+static float exact_scan_eps(int32_t dpad, bool mfma)
+{
+    const double u = 5.9604644775390625e-8;
+    const double e_dot = mfma ? (dpad / 2 + 8) * u : (dpad / 64 + 8) * u;
+    const double e_norm = (dpad / 64 + 8) * u;
+    return (float)(2.0 * 2.0 * (e_dot + e_norm + 2 * u));
 }
 
 template <int QT>
@@ -665,7 +700,6 @@ int exact_search(morna_index *h, const double *q, int64_t nq, int32_t k, int32_t
     if (nq == 0) return MORNA_OK;
     const int64_t N = h->n_items;
     const int32_t D = h->dim, dpad = h->dpad;
-    const float eps = 1e-4f;   // >> fp32 scan error (DESIGN.md "Exact search"); more candidates, never fewer
     // queries resident per pass: their fp32 images share 64 KiB of LDS
     const int qt = (size_t)dpad * 4 * 8 <= 65536 ? 8 : (size_t)dpad * 4 * 4 <= 65536 ? 4
                    : (size_t)dpad * 4 * 2 <= 65536 ? 2 : 1;
@@ -707,6 +741,7 @@ int exact_search(morna_index *h, const double *q, int64_t nq, int32_t k, int32_t
             else launch_exact_scan<1>(h, N, nb, Qf.p, qn2.p, approx.p);
         }
         HIP_TRY(hipGetLastError());
+        const float eps = exact_scan_eps(dpad, nb >= 32);   // which scan ran
         for (;;) {
             MORNA_TRY(cand.alloc((size_t)batch * cap));
             MORNA_TRY(cdist.alloc((size_t)batch * cap));

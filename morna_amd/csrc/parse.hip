@@ -236,6 +236,11 @@ int morna_parse_intropolis(const char *path, int64_t sample_count, int64_t sampl
             } else {
                 id = f->second;
             }
+            if (covs[i] > INT32_MAX || covs[i] < INT32_MIN) {   // the staged arrays are int32; the reference keeps Python ints
+                set_error("coverage %lld on line %lld of %s does not fit 32 bits", (long long)covs[i], (long long)lineno, path);
+                delete L;
+                return MORNA_E_INVALID;
+            }
             L->item_ids.push_back(id);
             L->cov.push_back((int32_t)covs[i]);
         }

@@ -20,6 +20,9 @@
 // by.  The (row, node) pairs the filter cannot decide -- about 0.5 % -- are listed and recomputed by
 // split_amb_kernel with wave_dot on the fp32 data, including the dot == 0 coin flip.  The sides written
 // are therefore exactly those of split_kernel; the forest stays bit-identical to the oracle.
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.hpp"
 #include "devutil.hpp"
 
@@ -350,6 +353,16 @@ int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, co
     hipLaunchKernelGGL(split_amb_kernel, dim3((unsigned)(4 * h->n_cus)), dim3(256), 0, h->stream, h->X.p, N, h->dpad, d_tasks,
                        row_pos, seed, hp_level, amb_count, amb, (unsigned int)cap, side, ones);
     HIP_TRY(hipGetLastError());
+    // MORNA_DEBUG_OPEN=1: how many (row, tree) pairs the filter of this level left to the canonical dot (stderr;
+    // costs a synchronisation, measurement only)
+    static const bool debug_open = getenv("MORNA_DEBUG_OPEN") && atoi(getenv("MORNA_DEBUG_OPEN")) != 0;
+    if (debug_open) {
+        unsigned int n_open = 0;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipMemcpy(&n_open, amb_count, 4, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[morna] split_mm level: D=%d split nodes=%d (row, tree) pairs<=%lld open=%u (%.4f %%)\n", h->dim,
+                n_tasks, (long long)cap, n_open, 100.0 * n_open / (double)cap);
+    }
     return MORNA_OK;
 }
 

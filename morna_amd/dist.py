@@ -124,7 +124,11 @@ class ShardedSearch(object):
         gids = np.where(ids >= 0, ids.astype(np.int64) + self.offsets[self.rank], -1)
         all_ids = self._all_gather_np(gids)
         all_d = self._all_gather_np(np.ascontiguousarray(d, np.float64))
-        return merge_topk_exact(all_ids, all_d, k)
+        out_ids, out_d, counts = merge_topk_exact(all_ids, all_d, k)
+        # count -1 = "the reference raises ValueError for this query" (a row whose cosine_distance has a negative
+        # radicand): true of the whole matrix as soon as it is true of one shard
+        failed = (self._all_gather_np(np.ascontiguousarray(cnt, np.int32)) < 0).any(axis=0)
+        return out_ids, out_d, np.where(failed, -1, counts).astype(np.int32)
 
     def get_nns_by_local_items(self, items, k, search_k=-1):
         """Each rank contributes the rows of some of its own items as queries

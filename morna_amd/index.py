@@ -100,15 +100,22 @@ class MornaIndex(AnnoyIndex):
             return
         self.sample_frequencies[junction] += len(samples)
         idf_value = log(float(self.sample_count) / self.sample_frequencies[junction])
-        ids = np.empty(len(samples), np.int32)
+        # the reference walks zip(samples, coverages): a longer list is cut to the shorter one, and only the
+        # samples it reaches get internal ids (the threshold and the frequency above use len(samples))
+        n = min(len(samples), len(coverages))
+        ids = np.empty(n, np.int32)
         id_map = self.internal_id_map
-        for t, sample_id in enumerate(samples):
+        for t in range(n):
+            sample_id = samples[t]
             internal_id = id_map.get(sample_id)
             if internal_id is None:
                 internal_id = id_map[sample_id] = self.new_internal_id
                 self.new_internal_id += 1
             ids[t] = internal_id
-        self._lines.append(junction.encode("ascii"), ids, np.asarray(coverages, dtype=np.int32), idf_value)
+        cov = np.asarray(coverages[:n], dtype=np.int64)
+        if n and (cov.max() > 2**31 - 1 or cov.min() < -2**31):
+            raise OverflowError("coverage of junction %r does not fit 32 bits (the staged arrays are int32)" % (junction,))
+        self._lines.append(junction.encode("ascii"), ids, cov.astype(np.int32), idf_value)
 
     def build(self, n_trees, verbose=False, seed=0):
         """Feature matrix on the GPU, then the forest (morna.py:390-425)."""

@@ -49,34 +49,36 @@ class MornaSearch(object):
             self.internal_id_map = pickle.load(pickle_stream)
 
     def inverse_lookup(self, internal_id):
-        """sample id whose internal id is `internal_id` (morna.py:552-572)."""
-        match = None
-        found_one_already = False
-        for sample_id in self.internal_id_map.keys():
-            if self.internal_id_map[sample_id] == internal_id:
-                match = sample_id
-                if found_one_already:
-                    raise RuntimeError(str(internal_id) + " does not have unique mapping in self.internal_id_map.")
-                found_one_already = True
-        return match
+        """External sample id that owns `internal_id`, None when nobody does (contract of morna.py:552-572:
+        the map is one-to-one, a second owner is a RuntimeError)."""
+        owners = [sample_id for sample_id, mapped in self.internal_id_map.items() if mapped == internal_id]
+        if len(owners) > 1:
+            raise RuntimeError(str(internal_id) + " does not have unique mapping in self.internal_id_map.")
+        return owners[0] if owners else None
 
     def update_query(self, junction):
         """Sum the coverage of one (chrom, start, end, coverage, ...) junction (morna.py:597-607)."""
         self.query[tuple(junction[:3])] += int(junction[3])
 
     def finalize_query(self):
-        """Dense fp64 query vector from the coverage dict (morna.py:609-629)."""
-        self.query_sample = [0.0 for _ in range(self.dim)]
-        for junction in self.query.keys():
-            hashable_junction = ' '.join(str(_) for _ in junction)
-            if self.sample_frequencies[hashable_junction] == 0:
-                idf_value = 0
-            else:
-                idf_value = log(float(self.sample_count) / self.sample_frequencies[hashable_junction])
-            key = hashable_junction.encode("ascii")
-            hash_value = int(_lib.lib().morna_hash32(key, len(key)))       # mmh3.hash
-            multiplier = (-1 if hash_value < 0 else 1)
-            self.query_sample[hash_value % self.dim] += (multiplier * (self.query[junction] * idf_value))
+        """query_sample from the summed coverages (arithmetic contract of morna.py:609-629).
+
+        One term per distinct junction, in the dict's insertion order: weight = log(sample_count / df) with the
+        index's FINAL document frequency of the key "chrom start end" (0 for a junction the index never saw),
+        term = coverage * weight, added with the sign of the key's 32-bit hash into column hash mod dim (Python's
+        floored modulo), all in fp64 -- the terms a column receives are added in that order.
+        """
+        hash32 = _lib.lib().morna_hash32
+        dense = [0.0] * self.dim
+        for parts, coverage in self.query.items():
+            text = ' '.join(map(str, parts))
+            df = self.sample_frequencies.get(text, 0)
+            weight = log(float(self.sample_count) / df) if df else 0
+            raw = text.encode("ascii")
+            h = int(hash32(raw, len(raw)))          # mmh3.hash: signed
+            term = coverage * weight
+            dense[h % self.dim] += -term if h < 0 else term
+        self.query_sample = dense
 
     def _with_meta(self, results, meta_db):
         """Append the metadata keywords of each result (morna.py:666-676)."""
@@ -100,8 +102,10 @@ class MornaSearch(object):
         ids, d, cnt = self.annoy_index.exact_search_batch(np.array([self.query_sample], dtype=np.float64),
                                                           num_neighbors)
         m = int(cnt[0])
-        if m and np.isnan(d[0, :m]).any():
-            raise ValueError("math domain error")     # math.sqrt of a negative radicand in the reference
+        if m < 0:
+            # some indexed row gives cosine_distance a negative radicand: the reference's math.sqrt raises while it
+            # walks the rows (morna.py:101-114, 697-700), whatever that row's rank would have been
+            raise ValueError("math domain error")
         results = ([int(x) for x in ids[0, :m]],)
         if include_distances:
             results += ([float(x) for x in d[0, :m]],)

@@ -18,38 +18,41 @@ def junctions_from_raw_stream(raw_stream):
         yield (tokens[0], int(tokens[1]), int(tokens[2]), int(tokens[3]))
 
 
+def _block_field(field):
+    """Items of a BED12 blockSizes / blockStarts field.  UCSC writes the lists with a closing comma, so a
+    last item that is not a number is not an item; the others are converted where they are used."""
+    items = field.split(',')
+    try:
+        int(items[-1])
+    except ValueError:
+        items.pop()
+    return items
+
+
 def junctions_from_bed_stream(bed_stream):
-    """BED12 lines of a junctions file (utils.py:206-252)."""
+    """Introns of BED12 alignment lines (the format utils.py:206-252 reads).
+
+    A BED12 line places n blocks (exons) at chromStart + blockStarts[i], blockSizes[i] long, 0-based half
+    open; the n - 1 gaps between consecutive blocks are the junctions, reported 1-based inclusive with the
+    line's score column as coverage.  Lines with fewer than 12 columns or fewer than 2 blocks carry none.
+    """
     for line in bed_stream:
-        tokens = line.rstrip().split('\t')
-        if len(tokens) < 12:
+        columns = line.rstrip().split('\t')
+        if len(columns) < 12:
             continue
-        chrom = tokens[0]
-        chrom_start = int(tokens[1])
-        coverage = int(tokens[4])
-        block_sizes = tokens[10].split(',')
-        block_starts = tokens[11].split(',')
-        # Handle trailing commas
-        try:
-            int(block_sizes[-1])
-        except ValueError:
-            block_sizes = block_sizes[:-1]
-        try:
-            int(block_starts[-1])
-        except ValueError:
-            block_starts = block_starts[:-1]
-        block_count = len(block_sizes)
-        if block_count < 2:
+        origin, coverage = int(columns[1]), int(columns[4])
+        sizes, offsets = _block_field(columns[10]), _block_field(columns[11])
+        n_blocks = len(sizes)
+        if n_blocks < 2:
             continue
-        assert block_count == len(block_starts)
-        junctions = [chrom_start + int(block_starts[0]) + int(block_sizes[0])]
-        for i in range(1, block_count - 1):
-            junction_start = chrom_start + int(block_starts[i])
-            junctions.append(junction_start)
-            junctions.append(junction_start + int(block_sizes[i]))
-        junctions.append(chrom_start + int(block_starts[-1]))
-        for i in range(len(junctions) // 2):
-            yield (chrom, junctions[2 * i] + 1, junctions[2 * i + 1], coverage)
+        assert n_blocks == len(offsets)
+        introns = []
+        for left in range(n_blocks - 1):
+            last_exon_base = origin + int(offsets[left]) + int(sizes[left])     # 0-based end = 1-based last base
+            next_exon_base = origin + int(offsets[left + 1])                     # 0-based start of the next block
+            introns.append((last_exon_base + 1, next_exon_base))
+        for first, last in introns:
+            yield (columns[0], first, last, coverage)
 
 
 def _cigar_junctions(cigar, pos):

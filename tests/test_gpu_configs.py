@@ -1,0 +1,282 @@
+"""BASELINE.json's configurations, each exactly as stated, under -m gpu.
+
+  configs[2]  synthetic intropolis 50k samples x 3000 features, 200 trees, 1000 by-item queries, k = 20,
+              search_k = 100 -- built as bench.py builds it: feature matrix bit-exact against the oracle; the first
+              trees of the forest node for node against oracle mode 1 (a tree's Kiss32 streams depend on its own
+              number only, so tree t of a 200-tree forest IS tree t of an 8-tree forest); invariants over all 200;
+              every returned distance = the fp64 angular distance of the returned id; recall@20 against the exact
+              search, and against the FAITHFUL annoy restatement (oracle mode 0) at 24 trees, same search_k.
+  configs[3]  the 25k x 3000 shard a GPU holds of the 200k-sample index, through ShardedSearch on a 1-rank RCCL
+              group (the 8-GPU run itself is the driver's).
+  configs[4]  50k x 8192 exact all-pairs: one GPU's 6250-row shard, all 6250 rows as queries (morna.py:681-716
+              for every item), ids and fp64 distances against the oracle on a 64-query sample.
+
+Parity unpinned for the forest at N > K (no reference fixture has N > K, annoy is absent): what is pinned is the
+feature matrix and the exact search; the forest is compared with this repository's restatements of annoy.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from test_gpu_scale import _check_forest, _true_ang
+
+pytestmark = pytest.mark.gpu
+
+D3, T3, Q3, K3, SEARCH_K = 3000, 200, 1000, 20, 100
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from oracle import capi as c
+    c.lib()
+    return c
+
+
+@pytest.fixture(scope="module")
+def c3():
+    """configs[2], as bench.py's default run builds it."""
+    from morna_amd.annoy import AnnoyIndex
+    from morna_amd.index import prepare_csr
+    from morna_amd.synth import query_items, synthetic_intropolis
+    data = synthetic_intropolis(50_000, J=70_000)
+    prep = prepare_csr(data["keys"], data["row_ptr"], data["samples"], data["cov"], data["sample_count"], 100)
+    a = AnnoyIndex(D3)
+    a.stage_junctions(prep["key_bytes"], prep["key_off"], prep["row_ptr"], prep["ids"], prep["cov"], prep["idf"])
+    a.build_features(prep["n_items"])
+    a.build(T3, seed=0)
+    X = a.get_items()
+    items = query_items(prep["n_items"], Q3)
+    return dict(index=a, data=data, prep=prep, X=X, items=items, N=prep["n_items"])
+
+
+def test_c3_feature_matrix_bit_exact_vs_oracle(c3, capi):
+    """morna.py:344-388 + the fp64 -> fp32 hand-off of 405-424 over all 1e8 (sample, coverage) pairs."""
+    data = c3["data"]
+    buf, off = capi.pack_keys(data["keys"])
+    ref = capi.index_features(buf, off, data["row_ptr"], data["samples"], data["cov"], data["sample_count"], 100, D3,
+                              max_items=c3["N"])
+    assert ref["n_items"] == c3["N"] == 50_000
+    assert ref["ext_ids"].tolist() == c3["prep"]["ext_ids"].tolist()
+    assert c3["X"].tobytes() == ref["X"].tobytes()
+
+
+def _compare_tree(f, hp_of, o, gpu_root, ora_root):
+    """One tree of the GPU forest against one tree of the oracle's, by structure (node ids differ when the two
+    forests have different numbers of trees)."""
+    rec, perm = f["node_rec"], f["perm"]
+    stack, n = [(gpu_root, ora_root)], 0
+    while stack:
+        g, r = stack.pop()
+        nd = o.node(r)
+        kind, tree, start, count, c0, c1 = [int(x) for x in rec[g]]
+        assert kind == nd["kind"] and count == nd["n_desc"], (g, r)
+        if kind == 1:
+            assert perm[tree, start:start + count].tolist() == nd["items"].tolist(), (g, r)
+        else:
+            assert f["hyperplanes"][hp_of[g]].tobytes() == nd["v"].tobytes(), (g, r)
+            stack.append((c0, nd["child0"]))
+            stack.append((c1, nd["child1"]))
+        n += 1
+    return n
+
+
+def test_c3_forest_invariants_and_first_trees_vs_oracle(c3, capi):
+    a, N = c3["index"], c3["N"]
+    st = _check_forest(a, N, T3, D3 + 2)
+    assert st["max_depth"] >= 5                       # ceil(log2(50000 / 3002)) = 5
+    n_ref = 6
+    o = capi.AnnoyOracle(D3, mode=1)
+    o.set_items(c3["X"])
+    o.build(n_ref)
+    f = a.get_forest()
+    hp_of = {int(n): i for i, n in enumerate(f["hp_node"])}
+    roots = o.roots()
+    nodes = sum(_compare_tree(f, hp_of, o, t, roots[t]) for t in range(n_ref))
+    assert nodes == o.n_nodes()
+
+
+def test_c3_queries_distances_and_recall_vs_exact(c3):
+    """1000 by-item queries at morna's defaults (k = 20, search_k = 100; morna.py:762-774, 892-896)."""
+    a, X, items = c3["index"], c3["X"], c3["items"]
+    ids, d, cnt = a.get_nns_by_item_batch(items, K3, SEARCH_K)
+    assert (cnt == K3).all()
+    for qi in range(0, Q3, 5):                        # every fifth query: fp64 distances of 4000 pairs on the host
+        it = int(items[qi])
+        assert ids[qi, 0] == it and d[qi, 0] < 1e-3
+        assert np.allclose(d[qi], _true_ang(X, X[it], ids[qi]), atol=2e-5)
+        key = list(zip(d[qi].tolist(), ids[qi].tolist()))
+        assert key == sorted(key) and len(set(ids[qi].tolist())) == K3
+    eids, ed, ecnt = a.exact_search_batch(X[items].astype(np.float64), K3)
+    assert (ecnt == K3).all()
+    recall = np.mean([len(set(ids[i].tolist()) & set(eids[i].tolist())) / float(K3) for i in range(Q3)])
+    assert recall >= 0.95, recall                     # one leaf of ~2500 rows holds a query's cluster mates
+    c3["recall_200_trees"] = float(recall)
+    c3["exact_ids"] = eids
+
+
+def test_c3_recall_vs_faithful_annoy_restatement(c3, capi):
+    """Stand-in for "within tolerance of the reference CPU path" (annoy itself is not installable): the faithful
+    restatement (oracle mode 0: one sequential Kiss32 stream, depth-first) and the GPU forest, both with 24 trees
+    on the same 50k x 3000 matrix, same search_k = 100 and k = 20, on 120 queries.  Tolerance: recall@20 of the
+    GPU forest >= the restatement's - 0.05 (both against the exact search)."""
+    from morna_amd.annoy import AnnoyIndex
+    X, items = c3["X"], c3["items"][:120]
+    T = 24
+    o = capi.AnnoyOracle(D3, mode=0)
+    o.set_items(X)
+    o.build(T)
+    g = AnnoyIndex(D3)
+    g.add_items(X)
+    g.build(T)
+    eids = c3["index"].exact_search_batch(X[items].astype(np.float64), K3)[0]
+    ids, d, cnt = g.get_nns_by_item_batch(items, K3, SEARCH_K)
+    hit_g = hit_o = 0
+    for qi, it in enumerate(items):
+        true = set(eids[qi].tolist())
+        hit_g += len(true & set(ids[qi, :int(cnt[qi])].tolist()))
+        hit_o += len(true & set(o.get_nns_by_item(int(it), K3, SEARCH_K)))
+    rg, ro = hit_g / (K3 * len(items)), hit_o / (K3 * len(items))
+    assert rg >= ro - 0.05, (rg, ro)
+
+
+def test_c3_eight_trees_bit_exact_vs_oracle_mode1(c3, capi):
+    """The same matrix with 8 trees: whole forest and search results (k = 20, search_k = 100 and -1) equal to
+    oracle mode 1 -- the node-for-node check of test_gpu_parity.py at the headline row count."""
+    from morna_amd.annoy import AnnoyIndex
+    from test_gpu_parity import _compare_forest
+    X, N = c3["X"], c3["N"]
+    T = 8
+    o = capi.AnnoyOracle(D3, mode=1)
+    o.set_items(X)
+    o.build(T)
+    g = AnnoyIndex(D3)
+    g.add_items(X)
+    g.build(T)
+    st = g.forest_stats()
+    assert st["split_rows"] == o.split_rows() and st["split_attempts"] == o.split_nodes()
+    _compare_forest(g, o, N, T)
+    items = c3["items"][:48]
+    for sk in (SEARCH_K, -1):
+        ids, d, cnt = g.get_nns_by_item_batch(items, K3, sk)
+        for qi, it in enumerate(items):
+            rid, rd = o.get_nns_by_item(int(it), K3, sk, include_distances=True)
+            m = int(cnt[qi])
+            assert ids[qi, :m].tolist() == rid, (it, sk)
+            assert d[qi, :m].tobytes() == np.array(rd, np.float32).tobytes(), (it, sk)
+
+
+def test_c4_shard_25k_through_sharded_search_one_rank_rccl(capi):
+    """configs[3]: what ONE of the 8 GPUs does for the 200k-sample index -- a 25k x 3000 shard with its own
+    200-tree forest, queried through ShardedSearch (query rows stay in HBM, top-k all-gather over RCCL, merge)."""
+    import torch
+    import torch.distributed as dist
+    from morna_amd.annoy import AnnoyIndex
+    from morna_amd.dist import ShardedSearch
+    from morna_amd.index import prepare_csr
+    from morna_amd.synth import query_items, synthetic_intropolis
+    data = synthetic_intropolis(25_000, J=70_000)
+    prep = prepare_csr(data["keys"], data["row_ptr"], data["samples"], data["cov"], data["sample_count"], 100)
+    N = prep["n_items"]
+    a = AnnoyIndex(D3)
+    a.stage_junctions(prep["key_bytes"], prep["key_off"], prep["row_ptr"], prep["ids"], prep["cov"], prep["idf"])
+    a.build_features(N)
+    a.build(T3, seed=0)
+    _check_forest(a, N, T3, D3 + 2)
+    X = a.get_items()
+    # the shard's matrix against the oracle on a prefix of the lines is covered at 50k; here: rows vs the oracle for
+    # the first 2000 junction lines only would need a second build -- instead the cheap invariant: no empty row
+    assert (np.abs(X).sum(1) > 0).all()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ss = ShardedSearch(a, 0, 1, N)
+        items = query_items(N, Q3)
+        ids, d, cnt = ss.get_nns_by_local_items(items, K3, SEARCH_K)
+        want = a.get_nns_by_item_batch(items, K3, SEARCH_K)
+        assert ids.tolist() == want[0].astype(np.int64).tolist()
+        assert np.asarray(d, np.float32).tobytes() == want[1].tobytes() and cnt.tolist() == want[2].tolist()
+        eids, ed, ecnt = ss.exact_search(X[items[:200]].astype(np.float64), K3)
+        recall = np.mean([len(set(ids[i].tolist()) & set(eids[i].tolist())) / float(K3) for i in range(200)])
+        assert recall >= 0.95, recall
+        for qi in range(0, 200, 8):
+            rid, rd = capi.exact_search(X, X[items[qi]].astype(np.float64), K3)
+            assert eids[qi].tolist() == rid.tolist() and ed[qi].tobytes() == rd.tobytes()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c5_exact_all_pairs_shard_8192(capi):
+    """configs[4]: exact brute-force all-pairs k-NN at D = 8192 on one GPU's shard of the 50k samples (6250 rows):
+    morna.py:681-716 run with every indexed row as the query.  TF-IDF rows of the synthetic intropolis: cluster
+    mates are strongly correlated and their distances to a query nearly tie, which is what the candidate window of
+    the fp32 matrix-core scan has to survive (knn.hip eps)."""
+    from morna_amd.annoy import AnnoyIndex
+    from morna_amd.index import prepare_csr
+    from morna_amd.synth import synthetic_intropolis
+    D, k = 8192, 20
+    data = synthetic_intropolis(6250, J=70_000)
+    prep = prepare_csr(data["keys"], data["row_ptr"], data["samples"], data["cov"], data["sample_count"], 100)
+    N = prep["n_items"]
+    assert N == 6250
+    a = AnnoyIndex(D)
+    a.stage_junctions(prep["key_bytes"], prep["key_off"], prep["row_ptr"], prep["ids"], prep["cov"], prep["idf"])
+    a.build_features(N)
+    X = a.get_items()
+    Q = X.astype(np.float64)
+    ids, d, cnt = a.exact_search_batch(Q, k)
+    assert (cnt == k).all()                            # no row of this data set is parallel to another
+    assert (ids[:, 0] == np.arange(N)).all() and (d[:, 0] == 0.0).all()   # sqrt(RN(pp * pp)) == pp: a row is at 0 from itself
+    assert (np.diff(d, axis=1) >= 0).all()
+    rng = np.random.default_rng(5)
+    for qi in rng.choice(N, 64, replace=False):
+        rid, rd = capi.exact_search(X, Q[qi], k)
+        assert ids[qi].astype(np.int64).tolist() == rid.tolist(), qi
+        assert d[qi].tobytes() == rd.tobytes(), qi
+    # the same through the few-queries path (vector-ALU scan): identical answers, whichever scan selects
+    ids2, d2, _ = a.exact_search_batch(Q[:16], k)
+    assert ids2.tolist() == ids[:16].tolist() and d2.tobytes() == d[:16].tobytes()
+
+
+def test_exact_search_row_parallel_to_the_query_raises(capi, tmp_path):
+    """cosine_distance (morna.py:101-114) takes math.sqrt(2 - 2 pq / sqrt(pp qq)): for a row all but parallel to
+    the query the radicand can round below zero and the reference raises ValueError -- for the whole query,
+    since it evaluates every row (morna.py:697-700).  The library reports such a query with count -1 whatever
+    rank the row would have had, and MornaSearch.exact_search_nn raises."""
+    from morna_amd.annoy import AnnoyIndex
+    rng = np.random.default_rng(99)
+    D, N = 96, 400
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    # scaled copies of one row: parallel in exact arithmetic, off by roundings in fp32/fp64; find a query for which
+    # the oracle (same fp64 operations as Python) does produce a NaN for some of them
+    for s in range(40):
+        X[100 + s] = X[7] * np.float32(1.0 + 0.37 * (s + 1))
+    q = None
+    for cand in range(100, 140):
+        qq = X[cand].astype(np.float64) * 1.7
+        dist = [capi.cosine_distance(X[r], qq) for r in [7] + list(range(100, 140))]
+        if np.isnan(dist).any():
+            q, n_nan = qq, int(np.isnan(dist).sum())
+            break
+    assert q is not None, "no negative radicand among 40 x 41 near-parallel pairs"
+    a = AnnoyIndex(D)
+    a.add_items(X)
+    a.build(2)
+    for k in (3, 60):                                  # k below and above the number of parallel rows
+        ids, d, cnt = a.exact_search_batch(np.stack([q, rng.standard_normal(D)]), k)
+        assert cnt[0] == -1 and cnt[1] == k
+    # through the reference-shaped front end
+    from morna_amd.search import MornaSearch
+    s = MornaSearch.__new__(MornaSearch)
+    s.annoy_index, s.query_sample, s.basename = a, [float(v) for v in q], str(tmp_path / "x")
+    with pytest.raises(ValueError):
+        s.exact_search_nn(3)
+    s.query_sample = [float(v) for v in rng.standard_normal(D)]
+    assert len(s.exact_search_nn(3)[0]) == 3

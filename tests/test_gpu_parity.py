@@ -404,3 +404,55 @@ def test_save_load_roundtrip(tmp_path):
     assert got[0].tolist() == want[0].tolist() and got[1].tobytes() == want[1].tobytes()
     with pytest.raises(IOError):
         AnnoyIndex(25).load(str(tmp_path / "t.annoy.mor"))
+
+
+def test_load_rejects_damaged_files(tmp_path):
+    """A truncated or inconsistent index blob is an IOError, not a crash, an out-of-bounds read on the device or an
+    exception thrown across the C ABI: header against the file size, node tables, permutation."""
+    import struct
+    from morna_amd.annoy import AnnoyIndex
+    rng = np.random.default_rng(6)
+    X = _clustered(rng, 900, 12)
+    a = AnnoyIndex(12)
+    a.add_items(X)
+    a.build(3)
+    path = str(tmp_path / "ok.annoy.mor")
+    a.save(path)
+    blob = open(path, "rb").read()
+    st = a.forest_stats()
+    hdr = 8 + 4 + 4 + 8 + 8 + 8 + 4 + 4 + 11 * 8
+    assert len(blob) == hdr + 4 * 900 * 12 + 4 * 3 * 900 + 4 * 6 * st["n_nodes"] + 4 * st["n_split"] * 12
+
+    def attempt(data):
+        p = str(tmp_path / "bad.annoy.mor")
+        with open(p, "wb") as fh:
+            fh.write(data)
+        b = AnnoyIndex(12)
+        with pytest.raises(IOError):
+            b.load(p)
+        assert b.get_n_items() == 0                       # nothing half-loaded is left behind
+        with pytest.raises(RuntimeError):
+            b.get_nns_by_item(0, 3)
+
+    attempt(blob[:len(blob) // 2])                        # truncated
+    attempt(blob + b"\0\0\0\0")                           # trailing bytes
+    attempt(blob[:16] + struct.pack("<q", 2 ** 40) + blob[24:])          # n_items the file cannot hold
+    attempt(blob[:24] + struct.pack("<q", st["n_nodes"] + 2) + blob[32:])  # n_nodes != n_trees + 2 n_split
+    rows_end = hdr + 4 * 900 * 12
+    bad = bytearray(blob)
+    bad[rows_end:rows_end + 4] = struct.pack("<i", 900)   # perm entry == n_items
+    attempt(bytes(bad))
+    rec0 = rows_end + 4 * 3 * 900
+    bad = bytearray(blob)
+    bad[rec0:rec0 + 4] = struct.pack("<i", 0)             # root 0's first child is itself: a cycle
+    attempt(bytes(bad))
+    bad = bytearray(blob)
+    bad[rec0 + 12:rec0 + 16] = struct.pack("<i", 901)     # root count beyond the items
+    attempt(bytes(bad))
+    hp0 = rec0 + 4 * 4 * st["n_nodes"] + 4 * st["n_nodes"]
+    bad = bytearray(blob)
+    bad[hp0:hp0 + 4] = struct.pack("<i", st["n_split"])   # hyperplane slot out of range
+    attempt(bytes(bad))
+    b = AnnoyIndex(12)
+    b.load(path)                                          # and the intact file still loads
+    assert b.get_nns_by_item(5, 4, -1) == a.get_nns_by_item(5, 4, -1)

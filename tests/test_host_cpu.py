@@ -175,6 +175,32 @@ def test_native_parser_tiny_intropolis_and_errors(tmp_path):
     _write(p, ["chr1\t1\t2\t+\tGT\tAG\t7,x\t1,1\n"], False)
     with pytest.raises(ValueError):
         mindex.ParsedLines(p, 5, 1)
+    _write(p, ["chr1\t1\t2\t+\tGT\tAG\t7,8\t1,4294967297\n"], False)      # a coverage the int32 arrays cannot hold
+    with pytest.raises(ValueError):
+        mindex.ParsedLines(p, 5, 1)
+
+
+def test_add_junction_ragged_lists_follow_zip():
+    """morna.py:376: `for sample_id, coverage in zip(samples, coverages)` -- the longer list is cut, the threshold
+    and the frequency still use len(samples), and only the samples the loop reaches get internal ids.  The Python
+    path and the native parser (test above) agree on that."""
+    from math import log
+    m = mindex.MornaIndex.__new__(mindex.MornaIndex)      # no device needed for the host half
+    m.sample_count, m.sample_threshold, m.skipped, m.junc_id = 20, 2, 0, -1
+    m.internal_id_map, m.new_internal_id = {}, 0
+    from collections import defaultdict
+    m.sample_frequencies = defaultdict(int)
+    m._lines = mindex.JunctionBuffer()
+    m.add_junction("chr1 1 2", [7, 9], [1, 1])
+    m.add_junction("chr1 1 2", [9, 3, 7], [5, 6])          # coverages shorter: sample 7 is not reached here
+    m.add_junction("chr2 5 6", [4, 11], [1, 2, 3])         # coverages longer: the extra one is dropped
+    m.add_junction("chr3 1 9", [5], [1])                   # below the threshold
+    key_bytes, key_off, row_ptr, ids, cov, idf = m._lines.arrays()
+    assert row_ptr.tolist() == [0, 2, 4, 6] and ids.tolist() == [0, 1, 1, 2, 3, 4] and cov.tolist() == [1, 1, 5, 6, 1, 2]
+    assert idf.tolist() == [log(20.0 / 2), log(20.0 / 5), log(20.0 / 2)]
+    assert m.internal_id_map == {7: 0, 9: 1, 3: 2, 4: 3, 11: 4} and m.skipped == 1 and m.junc_id == 3
+    with pytest.raises(OverflowError):
+        m.add_junction("chr4 1 2", [1, 2], [1, 2 ** 31])
 
 
 def test_pretokenised_cache_roundtrip_and_invalidation(tmp_path, embedded):
