@@ -106,8 +106,9 @@ def test_c3_queries_distances_and_recall_vs_exact(c3):
         it = int(items[qi])
         assert ids[qi, 0] == it and d[qi, 0] < 1e-3
         assert np.allclose(d[qi], _true_ang(X, X[it], ids[qi]), atol=2e-5)
-        key = list(zip(d[qi].tolist(), ids[qi].tolist()))
-        assert key == sorted(key) and len(set(ids[qi].tolist())) == K3
+        # ranked by (2 - 2 cos, id) as annoy does; the square root that is reported can make two different keys
+        # print equal: ascending distances, distinct ids
+        assert (np.diff(d[qi]) >= 0).all() and len(set(ids[qi].tolist())) == K3
     eids, ed, ecnt = a.exact_search_batch(X[items].astype(np.float64), K3)
     assert (ecnt == K3).all()
     recall = np.mean([len(set(ids[i].tolist()) & set(eids[i].tolist())) / float(K3) for i in range(Q3)])

@@ -76,8 +76,9 @@ def test_full_size_forest_and_search_properties(N, D, T):
         for qi, it in enumerate(items):
             assert ids[qi, 0] == it and d[qi, 0] < 1e-3                        # an item is its own nearest neighbour
             assert np.allclose(d[qi], _true_ang(X, X[it], ids[qi]), atol=2e-5)
-            key = list(zip(d[qi].tolist(), ids[qi].tolist()))
-            assert key == sorted(key) and len(set(ids[qi].tolist())) == 20
+            # ranked by (2 - 2 cos, id) as annoy does; the square root that is reported can make two different keys
+            # print equal: ascending distances, distinct ids
+            assert (np.diff(d[qi]) >= 0).all() and len(set(ids[qi].tolist())) == 20
     eids, ed, _ = a.exact_search_batch(X[items].astype(np.float64), 20)
     rec = np.mean([len(set(ids[i].tolist()) & set(eids[i].tolist())) / 20.0 for i in range(len(items))])
     assert rec > 0.9                                                           # clustered data, search_k = 20 * T
