@@ -78,6 +78,21 @@ class AnnoyIndex(object):
                                             ptr(ids), ptr(d), ptr(cnt)))
         return ids, d, cnt
 
+    def get_nns_by_vector_packed(self, q_ptr, nq, n, search_k, id_offset, packed_ptr):
+        """Row-sharded search, device hand-over: answers to nq fp32 queries at q_ptr (host or device) written to
+        packed_ptr (this device's memory) as the [nq, 2n] int32 message of the top-k all-gather."""
+        check(lib().morna_get_nns_by_vector_packed(self._h, C.c_void_p(int(q_ptr)), int(nq), int(n), int(search_k),
+                                                   int(id_offset), C.c_void_p(int(packed_ptr))))
+
+    def merge_topk_packed(self, gathered_ptr, world, nq, kk, n):
+        """Merge of the all-gathered messages [world, nq, 2kk] (device memory) on the device."""
+        ids = np.empty((nq, n), np.int32)
+        d = np.empty((nq, n), np.float32)
+        cnt = np.empty(nq, np.int32)
+        check(lib().morna_merge_topk_packed(self._h, C.c_void_p(int(gathered_ptr)), int(world), int(nq), int(kk), int(n),
+                                            ptr(ids), ptr(d), ptr(cnt)))
+        return ids, d, cnt
+
     def get_items(self):
         out = np.empty((self.get_n_items(), self.f), dtype=np.float32)
         check(lib().morna_get_items(self._h, ptr(out)))

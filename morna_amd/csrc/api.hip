@@ -435,6 +435,30 @@ int morna_get_nns_by_item(morna_index *h, const int32_t *items, int64_t nq, int3
     return query_batch(h, nullptr, 0, items, nq, k, search_k, ids_out, dist_out, count_out);
 }
 
+int morna_get_nns_by_vector_packed(morna_index *h, const float *q, int64_t nq, int32_t k, int32_t search_k, int64_t id_offset,
+                                   int32_t *packed_dev)
+{
+    CHECK_H(h);
+    if (!q || !packed_dev) {
+        set_error("get_nns_by_vector_packed: null buffer");
+        return MORNA_E_INVALID;
+    }
+    if (id_offset < 0 || id_offset + h->n_items > (int64_t)INT32_MAX) {
+        set_error("get_nns_by_vector_packed: global ids past 2^31 do not fit the packed message");
+        return MORNA_E_RANGE;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    return query_batch(h, q, 0, nullptr, nq, k, search_k, nullptr, nullptr, nullptr, packed_dev, id_offset);
+}
+
+int morna_merge_topk_packed(morna_index *h, const int32_t *gathered_dev, int32_t world, int64_t nq, int32_t kk, int32_t k,
+                            int32_t *ids_out, float *dist_out, int32_t *count_out)
+{
+    CHECK_H(h);
+    HIP_TRY(hipSetDevice(h->device));
+    return merge_topk_dev(h, gathered_dev, world, nq, kk, k, ids_out, dist_out, count_out);
+}
+
 int morna_exact_search(morna_index *h, const double *q, int64_t nq, int32_t k, int32_t *ids_out, double *dist_out,
                        int32_t *count_out)
 {

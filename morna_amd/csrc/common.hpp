@@ -223,10 +223,16 @@ int hash_keys_device(morna_index *h, const uint8_t *key_bytes, const int64_t *ke
 int build_forest(morna_index *h, int32_t n_trees, uint32_t seed);
 // splitmm.hip: the split of a whole level on the matrix cores (fp16 filter, exact fp32 for what it cannot decide)
 int split_mm_prepare_rows(morna_index *h, hipStream_t stream);   // stream: the handle's main or side stream
+int split_mm_convert_rows(morna_index *h, const float *src, int64_t rows, _Float16 *dst, float *norm, float *err,
+                          float *inv_scale, hipStream_t stream);
 int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, const float *hp_level,
                    const int32_t *row_task, const int32_t *row_pos, uint32_t seed, uint8_t *side, int32_t *ones);
+// packed_dev (device memory, or null): [nq][2k] int32 message of the row-sharded search -- ids + id_offset, distance bits
 int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int32_t *items_host, int64_t nq, int32_t k,
-                int32_t search_k, int32_t *ids_out, float *dist_out, int32_t *count_out);
+                int32_t search_k, int32_t *ids_out, float *dist_out, int32_t *count_out, int32_t *packed_dev = nullptr,
+                int64_t id_offset = 0);
+int merge_topk_dev(morna_index *h, const int32_t *gathered_dev, int32_t world, int64_t nq, int32_t kk, int32_t k,
+                   int32_t *ids_out, float *dist_out, int32_t *count_out);
 int exact_search(morna_index *h, const double *q, int64_t nq, int32_t k, int32_t *ids_out,
                  double *dist_out, int32_t *count_out);
 

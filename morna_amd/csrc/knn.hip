@@ -16,6 +16,7 @@
 
 #include "common.hpp"
 #include "devutil.hpp"
+#include "mm16.hpp"
 
 namespace morna {
 
@@ -42,15 +43,26 @@ struct QueryParams {
     uint64_t *pq;              // [nq][n_nodes]
     int32_t *cand;             // [nq][cap]
     uint64_t *keys;            // [nq][cap]
+    float *low;                // [nq][cap] lower bound of a candidate's distance (filter modes)
+    int32_t *ncand;            // [nq] unique candidates found by the traversal (may exceed cap)
+    float *qpp;                // [nq] canonical dot(q, q)
     uint32_t *bm_global;       // [nq][bm_words] when the bitmap does not fit LDS
     int32_t *ids_out;          // [nq][k]
     float *dist_out;           // [nq][k]
     int32_t *count_out;        // [nq]
     unsigned long long *stat;  // rows read: hyperplane dots + unique candidates + query
-    // candidate filter on the fp16 image of the rows (splitmm.hip); null: every candidate gets the fp32 dot
+    // Candidate filter on the fp16 image of the rows (splitmm.hip); X16 null: every candidate gets the fp32 dot.
+    // scores null: the refine kernel takes the filter dots itself, row by row (fp16 row x fp32 query), and every
+    // filter distance is within `delta` of the canonical one.  scores set: they were taken for ALL rows at once on
+    // the matrix cores (query_scores_kernel) from the fp16 images of rows AND queries; the bound is then per pair,
+    // from the measured norms and rounding-error norms of the two images.
     const _Float16 *X16;       // [n_items][dpad], row r scaled by 2^e(r)
-    const float *xscale;       // [n_items] 2^-e(r)
-    float delta;               // bound on |distance from the fp16 row - distance from the fp32 row|
+    const float *xscale;       // [n_items] 2^-e(r); 0: the row has no fp16 image
+    const float *xn16, *xe16;  // [n_items] upper bounds of |y_r| and |2^e x_r - y_r|
+    float delta;
+    const float *scores;       // [nq][n_items]  sum_i y_r[i] g_q[i]
+    const float *qscale, *qn16, *qe16;   // per query image: indexed by the item id (by-item) or the query number
+    float eacc;
 };
 
 __device__ inline uint64_t pq_key(float d, int32_t node)
@@ -71,16 +83,17 @@ __device__ inline uint64_t block_min_u64(uint64_t v, uint64_t *s_red, int tid)
     return r;
 }
 
+// ---- traversal: annoy's _get_all_nns up to the candidate set (oracle/annoy_oracle.c:453-504) -------------------
+// One workgroup per query: all root margins (every wave takes trees), then the best-first descent by wave 0 (array
+// priority queue, bitmap de-duplication of the leaves' ids).  Leaves the unique candidates in cand[].
 template <bool BM_LDS>
-__global__ __launch_bounds__(Q_THREADS) void query_kernel(QueryParams P)
+__global__ __launch_bounds__(Q_THREADS) void query_traverse_kernel(QueryParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *qv = (float4 *)smem;
     uint32_t *bm = BM_LDS ? (uint32_t *)(smem + (size_t)P.dpad * sizeof(float))
                           : P.bm_global + (size_t)blockIdx.x * P.bm_words;
-    __shared__ uint64_t s_red[Q_WAVES];
     __shared__ int s_ncand;
-    __shared__ float s_pp;
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const int64_t qi = blockIdx.x;
@@ -96,14 +109,13 @@ __global__ __launch_bounds__(Q_THREADS) void query_kernel(QueryParams P)
 
     uint64_t *pq = P.pq + qi * P.n_nodes;
     int32_t *cand = P.cand + qi * P.cap;
-    uint64_t *keys = P.keys + qi * P.cap;
     const bool roots_split = P.n_items > P.K;   // every root is a split node (count = N > K)
 
     // ---- phase 1: the roots all sit at +inf and are expanded before anything else;
     //      their margins are independent, so every wave takes a share.
-    if (w == 0) {
+    if (w == Q_WAVES - 1) {
         float pp = wave_dot(qv, qv, nvec, lane);
-        if (lane == 0) s_pp = pp;
+        if (lane == 0) P.qpp[qi] = pp;
     }
     if (roots_split) {
         for (int t = w; t < T; t += Q_WAVES) {
@@ -121,8 +133,8 @@ __global__ __launch_bounds__(Q_THREADS) void query_kernel(QueryParams P)
 
     // ---- phase 2: best-first traversal by wave 0 (max-heap semantics on (bound, node id));
     //      the queue is an unsorted array scanned by the wave, popped slots are zeroed.
-    int ndots = roots_split ? T : 0;
     if (w == 0) {
+        int ndots = roots_split ? T : 0;
         int hn = roots_split ? 2 * T : T;
         int64_t nn = 0;
         const int64_t search_k = P.search_k;
@@ -161,54 +173,152 @@ __global__ __launch_bounds__(Q_THREADS) void query_kernel(QueryParams P)
                 ndots++;
             }
         }
+        if (lane == 0) {   // (LDS operations of a wave complete in order: the count includes the last leaf's atomics)
+            const int nc = s_ncand;
+            P.ncand[qi] = nc;
+            atomicAdd(P.stat, (unsigned long long)(ndots + (nc < P.cap ? nc : P.cap) + 1));
+        }
+    }
+}
+
+// ---- filter dots of a whole batch on the matrix cores ----------------------------------------------------------
+// scores[q][r] = sum_i g_q[i] y_r[i] for ALL rows r and all queries q of the batch, from the fp16 images: a
+// nq x N x dpad contraction that reads the fp16 matrix once (0.3 GB at 50k x 3000) where the per-query form gathers
+// every query's ~K candidate rows separately (12 GB for 1000 queries).  It does ~N / K times the arithmetic the
+// candidates need, which the matrix cores deliver in less time than the gathers take while
+// nq * K >> N.  Queries are the A side (m), rows the B side (n): 32 lanes hold 32 consecutive rows of one query, so
+// the result goes out in 128-byte runs.  qrow: row of Q16 that holds query q (by-item queries point into the
+// matrix's own image), or null for the identity.
+__global__ __launch_bounds__(MM16_THREADS) void query_scores_kernel(const _Float16 *__restrict__ X16, int64_t n_items, int32_t dpad,
+                                                                    const _Float16 *__restrict__ Q16,
+                                                                    const int32_t *__restrict__ qrow, int32_t nq,
+                                                                    float *__restrict__ scores)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int32_t s_qrow[MM16_TILE];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int wm = w >> 1, wn = w & 1;
+    // workgroup b runs on XCD b % 8: an XCD takes every 8th row tile and walks that tile's query tiles back to back,
+    // so the row tile comes from HBM once and then from that XCD's L2
+    const int n_ct = (nq + MM16_TILE - 1) / MM16_TILE;
+    const int64_t row_tile = (int64_t)((blockIdx.x >> 3) / n_ct) * 8 + (blockIdx.x & 7);
+    const int64_t r0 = row_tile * MM16_TILE;
+    const int c0 = (int)((blockIdx.x >> 3) % n_ct) * MM16_TILE;
+    if (r0 >= n_items) return;
+    if (tid < MM16_TILE) {
+        const int q = c0 + tid < nq ? c0 + tid : nq - 1;
+        s_qrow[tid] = qrow ? qrow[q] : q;
     }
     __syncthreads();
-
-    // ---- phase 3: angular distance to every unique candidate row
-    const int ncand = s_ncand < P.cap ? s_ncand : P.cap;
-    const float pp = s_pp;
-    if (P.X16 && ncand > P.k) {
-        // 3a. FILTER: distances from the fp16 rows (half the bytes of the fp32 rows).  Each is within delta of the
-        // distance phase 3b would compute, so the k smallest exact distances are among the candidates whose
-        // filter distance is at most (k-th smallest filter distance) + 2 delta: only those get the fp32 dot.
-        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-        const int nv8 = P.dpad / 8;
-        for (int c = w; c < ncand; c += Q_WAVES) {
-            const int32_t id = cand[c];
-            const f16x8 *y = (const f16x8 *)(P.X16 + (int64_t)id * P.dpad);
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            auto mac8 = [&](const f16x8 hv, int i) {
-                const float4 qa = qv[2 * i], qb = qv[2 * i + 1];
-                s0 = fmaf((float)hv[0], qa.x, s0);
-                s1 = fmaf((float)hv[1], qa.y, s1);
-                s2 = fmaf((float)hv[2], qa.z, s2);
-                s3 = fmaf((float)hv[3], qa.w, s3);
-                s0 = fmaf((float)hv[4], qb.x, s0);
-                s1 = fmaf((float)hv[5], qb.y, s1);
-                s2 = fmaf((float)hv[6], qb.z, s2);
-                s3 = fmaf((float)hv[7], qb.w, s3);
-            };
-            int i = lane;
-            for (; i + 5 * WAVE < nv8; i += 6 * WAVE) {   // six 1-KiB loads in flight before the first use
-                const f16x8 h0 = y[i], h1 = y[i + WAVE], h2 = y[i + 2 * WAVE], h3 = y[i + 3 * WAVE];
-                const f16x8 h4 = y[i + 4 * WAVE], h5 = y[i + 5 * WAVE];
-                mac8(h0, i);
-                mac8(h1, i + WAVE);
-                mac8(h2, i + 2 * WAVE);
-                mac8(h3, i + 3 * WAVE);
-                mac8(h4, i + 4 * WAVE);
-                mac8(h5, i + 5 * WAVE);
+    mm16_f32x16 acc[2];
+    mm16_tile(X16, Q16, dpad, smem, [&](int rt) { return r0 + rt < n_items ? r0 + rt : n_items - 1; },
+              [&](int rt) { return (int64_t)s_qrow[rt]; }, acc);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int64_t r = r0 + wm * 32 + lr;
+    if (r < n_items) {
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int q = c0 + wn * 64 + tn * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (q < nq) scores[(int64_t)q * n_items + r] = acc[tn][e];
             }
-            for (; i < nv8; i += WAVE) mac8(y[i], i);
-            const float sc = P.xscale[id];   // 0: the row has no fp16 image (inf, NaN or below the scalable range)
-            const float dotf = wave_sum_xor((s0 + s1) + (s2 + s3)) * sc;
-            // such a row gets NaN: it sorts after every number, so it takes none of the k places that set the
-            // threshold, and it passes the test of 3b
-            const float df = sc != 0.f ? ang_dist(pp, P.norm2[id], dotf) : __int_as_float(0x7fc00000);
-            if (lane == 0) keys[c] = ((uint64_t)f32_orderable(df) << 32) | (uint32_t)c;
+    }
+}
+
+// ---- refine: angular distance to the candidates, k smallest (distance, id) --------------------------------------
+// FILTER (modes 1 and 2): a distance taken from fp16 data is within delta of the canonical fp32 one, so the k
+// smallest canonical distances are among the candidates whose lower bound does not exceed the k-th smallest upper
+// bound; only those get the canonical wave_dot, and the ranking is done on canonical values alone.  Candidates
+// without a usable fp16 value (inf, NaN, unscalable rows or queries) are never filtered out.
+template <int MODE>   // 0: no filter; 1: fp16 row x fp32 query per candidate (gather); 2: scores[] of the whole batch
+__global__ __launch_bounds__(Q_THREADS) void query_refine_kernel(QueryParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *qv = (float4 *)smem;
+    __shared__ uint64_t s_red[Q_WAVES];
+    __shared__ int s_nsurv;
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int64_t qi = blockIdx.x;
+    const int nvec = P.dpad / 4;
+    const float4 *src = P.items ? (const float4 *)(P.X + (int64_t)P.items[qi] * P.dpad)
+                                : (const float4 *)(P.Q + qi * P.dpad);
+    for (int i = tid; i < nvec; i += Q_THREADS) qv[i] = src[i];
+    if (tid == 0) s_nsurv = 0;
+    __syncthreads();
+
+    int32_t *cand = P.cand + qi * P.cap;
+    uint64_t *keys = P.keys + qi * P.cap;
+    const int ncand = P.ncand[qi] < P.cap ? P.ncand[qi] : P.cap;
+    const float pp = P.qpp[qi];
+    int nsel = ncand;          // candidates that get the canonical dot; their ids in cand[0 .. nsel)
+
+    if (MODE != 0 && ncand > P.k) {
+        float *low = P.low + qi * P.cap;
+        const float nan = __int_as_float(0x7fc00000);
+        if (MODE == 1) {
+            typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+            const int nv8 = P.dpad / 8;
+            for (int c = w; c < ncand; c += Q_WAVES) {
+                const int32_t id = cand[c];
+                const f16x8 *y = (const f16x8 *)(P.X16 + (int64_t)id * P.dpad);
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                auto mac8 = [&](const f16x8 hv, int i) {
+                    const float4 qa = qv[2 * i], qb = qv[2 * i + 1];
+                    s0 = fmaf((float)hv[0], qa.x, s0);
+                    s1 = fmaf((float)hv[1], qa.y, s1);
+                    s2 = fmaf((float)hv[2], qa.z, s2);
+                    s3 = fmaf((float)hv[3], qa.w, s3);
+                    s0 = fmaf((float)hv[4], qb.x, s0);
+                    s1 = fmaf((float)hv[5], qb.y, s1);
+                    s2 = fmaf((float)hv[6], qb.z, s2);
+                    s3 = fmaf((float)hv[7], qb.w, s3);
+                };
+                int i = lane;
+                for (; i + 5 * WAVE < nv8; i += 6 * WAVE) {   // six 1-KiB loads in flight before the first use
+                    const f16x8 h0 = y[i], h1 = y[i + WAVE], h2 = y[i + 2 * WAVE], h3 = y[i + 3 * WAVE];
+                    const f16x8 h4 = y[i + 4 * WAVE], h5 = y[i + 5 * WAVE];
+                    mac8(h0, i);
+                    mac8(h1, i + WAVE);
+                    mac8(h2, i + 2 * WAVE);
+                    mac8(h3, i + 3 * WAVE);
+                    mac8(h4, i + 4 * WAVE);
+                    mac8(h5, i + 5 * WAVE);
+                }
+                for (; i < nv8; i += WAVE) mac8(y[i], i);
+                const float sc = P.xscale[id];   // 0: the row has no fp16 image (inf, NaN or below the scalable range)
+                const float dotf = wave_sum_xor((s0 + s1) + (s2 + s3)) * sc;
+                const float df = sc != 0.f ? ang_dist(pp, P.norm2[id], dotf) : nan;
+                if (lane == 0) {
+                    // a NaN sorts after every number: it takes none of the k places that set the threshold
+                    keys[c] = ((uint64_t)f32_orderable(df + P.delta) << 32) | (uint32_t)c;
+                    low[c] = df - P.delta;
+                }
+            }
+        } else {
+            const int32_t qsrc = P.items ? P.items[qi] : (int32_t)qi;
+            const float qs = P.qscale[qsrc], qn = P.qn16[qsrc], qe = P.qe16[qsrc];
+            const float rq = qe / (qn * 0.996f);          // |f| / |g|, |g| from its upper bound less the slack put on it
+            const float *sc_row = P.scores + qi * P.n_items;
+            for (int c = tid; c < ncand; c += Q_THREADS) {
+                const int32_t id = cand[c];
+                const float sc = P.xscale[id] * qs;
+                const float rx = P.xe16[id] / (P.xn16[id] * 0.996f);
+                float df = nan, dl = 0.f;
+                if (sc != 0.f && rx < 0.125f && rq < 0.125f) {
+                    // |sum y g - s t x.q| <= (EACC |y| + |d|) |g| + (|y| + |d|) |f|, and s |x| >= |y| - |d|, t |q| >= |g| - |f|:
+                    // the cosine taken from the images is within this of the exact one
+                    const float cerr = ((P.eacc + rx) + (1.f + rx) * rq) / ((1.f - rx) * (1.f - rq));
+                    df = ang_dist(pp, P.norm2[id], sc_row[id] * sc);
+                    dl = 2.02f * cerr + 1e-5f;           // distance = 2 - 2 cos; the canonical norms and ang_dist's own rounding
+                }
+                keys[c] = ((uint64_t)f32_orderable(df + dl) << 32) | (uint32_t)c;
+                low[c] = df - dl;
+            }
         }
         __syncthreads();
-        uint64_t kth = 0;   // the k-th smallest filter key (keys are distinct: the candidate index is in them)
+        uint64_t kth = 0;   // the k-th smallest upper bound (keys are distinct: the candidate index is in them)
         for (int r = 0; r < P.k; r++) {
             uint64_t best = ~0ull;
             for (int c = tid; c < ncand; c += Q_THREADS) {
@@ -217,35 +327,34 @@ __global__ __launch_bounds__(Q_THREADS) void query_kernel(QueryParams P)
             }
             kth = block_min_u64(best, s_red, tid);
         }
-        const float thr = f32_from_orderable((uint32_t)(kth >> 32)) + 2.f * P.delta;
+        const float thr = f32_from_orderable((uint32_t)(kth >> 32));
+        // survivors, compacted to the front of keys[] as ids (order is irrelevant: the ranking below is by value)
         __syncthreads();
-        // 3b. the fp32 canonical dot for the survivors; the others can no longer be selected
-        for (int c = w; c < ncand; c += Q_WAVES) {
-            const float df = f32_from_orderable((uint32_t)(keys[c] >> 32));
-            uint64_t key = ~0ull;
-            if (!(df > thr)) {   // NaN stays in
-                const int32_t id = cand[c];
-                const float pqv = wave_dot((const float4 *)(P.X + (int64_t)id * P.dpad), qv, nvec, lane);
-                key = ((uint64_t)f32_orderable(ang_dist(pp, P.norm2[id], pqv)) << 32) | (uint32_t)id;
-            }
-            if (lane == 0) keys[c] = key;
+        for (int c0 = 0; c0 < ncand; c0 += Q_THREADS) {
+            const int c = c0 + tid;
+            const bool in = c < ncand && !(low[c] > thr);   // NaN stays in
+            const int32_t id = c < ncand ? cand[c] : 0;
+            __syncthreads();                                // every cand[c] of this round is read before a slot is written
+            if (in) cand[atomicAdd(&s_nsurv, 1)] = id;      // slots < c0 + Q_THREADS: none beyond the round just read
+            __syncthreads();
         }
-    } else {
-        for (int c = w; c < ncand; c += Q_WAVES) {
-            const int32_t id = cand[c];
-            const float pqv = wave_dot((const float4 *)(P.X + (int64_t)id * P.dpad), qv, nvec, lane);
-            if (lane == 0) keys[c] = ((uint64_t)f32_orderable(ang_dist(pp, P.norm2[id], pqv)) << 32) | (uint32_t)id;
-        }
+        nsel = s_nsurv;
+    }
+    __syncthreads();
+    for (int c = w; c < nsel; c += Q_WAVES) {
+        const int32_t id = cand[c];
+        const float pqv = wave_dot((const float4 *)(P.X + (int64_t)id * P.dpad), qv, nvec, lane);
+        if (lane == 0) keys[c] = ((uint64_t)f32_orderable(ang_dist(pp, P.norm2[id], pqv)) << 32) | (uint32_t)id;
     }
     __syncthreads();
 
-    // ---- phase 4: k smallest (distance, id) pairs, in order
-    const int kout = P.k < ncand ? P.k : ncand;
+    // ---- k smallest (distance, id) pairs, in order
+    const int kout = P.k < nsel ? P.k : nsel;
     uint64_t prev = 0;
     bool have_prev = false;
     for (int r = 0; r < kout; r++) {
         uint64_t best = ~0ull;
-        for (int c = tid; c < ncand; c += Q_THREADS) {
+        for (int c = tid; c < nsel; c += Q_THREADS) {
             const uint64_t kk = keys[c];
             if ((!have_prev || kk > prev) && kk < best) best = kk;
         }
@@ -262,17 +371,27 @@ __global__ __launch_bounds__(Q_THREADS) void query_kernel(QueryParams P)
         P.ids_out[qi * P.k + r] = -1;
         P.dist_out[qi * P.k + r] = INFINITY;
     }
-    if (tid == 0) {
-        P.count_out[qi] = kout;
-        atomicAdd(P.stat, (unsigned long long)(ndots + ncand + 1));
-    }
+    if (tid == 0) P.count_out[qi] = kout;
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// [n][k] ids / distances of a batch -> the [n][2k] int32 message of the top-k all-gather: global ids, distance bits
+__global__ void pack_topk_kernel(const int32_t *__restrict__ ids, const float *__restrict__ dist, int64_t total, int32_t k,
+                                 int32_t id_offset, int32_t *__restrict__ packed)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t q = i / k;
+    const int r = (int)(i - q * k);
+    const int32_t id = ids[i];
+    packed[q * 2 * k + r] = id >= 0 ? id + id_offset : -1;
+    packed[q * 2 * k + k + r] = __float_as_int(dist[i]);
+}
+
 // q_host: query vectors in host OR device memory (unified addressing), q_stride floats apart (0 = dim)
 int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int32_t *items_host, int64_t nq, int32_t k,
-                int32_t search_k, int32_t *ids_out, float *dist_out, int32_t *count_out)
+                int32_t search_k, int32_t *ids_out, float *dist_out, int32_t *count_out, int32_t *packed_dev, int64_t id_offset)
 {
     if (q_stride <= 0) q_stride = h->dim;
     if (!h->built) {
@@ -297,28 +416,38 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
     const int32_t cap = (int32_t)std::max<int64_t>(cap64, 1);
     const int32_t bm_words = (int32_t)((N + 31) / 32);
     const bool bm_lds = (size_t)bm_words * 4 <= 64 * 1024;
-    const size_t lds = (size_t)h->dpad * sizeof(float) + (bm_lds ? (size_t)bm_words * 4 : 0);
+    const size_t lds_q = (size_t)h->dpad * sizeof(float);
+    const size_t lds = lds_q + (bm_lds ? (size_t)bm_words * 4 : 0);
 
-    const size_t per_q = (size_t)h->n_nodes * 8 + (size_t)cap * 12 + (q_host ? (size_t)h->dpad * 4 : 0) +
-                         (bm_lds ? 0 : (size_t)bm_words * 4) + (size_t)k * 8 + 8;
+    // candidate filter on the fp16 rows (MORNA_QUERY_FILTER=0: every candidate gets the fp32 dot); pays when a
+    // query has many more candidates than results.  MORNA_QUERY_DENSE=0 keeps the per-candidate gather form.
+    static const bool filter_on = !(getenv("MORNA_QUERY_FILTER") && atoi(getenv("MORNA_QUERY_FILTER")) == 0);
+    static const bool dense_on = !(getenv("MORNA_QUERY_DENSE") && atoi(getenv("MORNA_QUERY_DENSE")) == 0);
+    const bool use_filter = filter_on && cap > 4 * (int64_t)k;
+    // the whole-batch contraction reads every fp16 row once; the gather form reads min(cap, ~K) rows per query
+    auto dense_pays = [&](int64_t nb) { return nb >= 64 && nb * std::min<int64_t>(cap, h->K) >= 2 * N; };
+    const bool may_dense = use_filter && dense_on && dense_pays(nq);
+
+    const size_t per_q = (size_t)h->n_nodes * 8 + (size_t)cap * 16 + (q_host ? (size_t)h->dpad * 6 + 16 : 0) +
+                         (bm_lds ? 0 : (size_t)bm_words * 4) + (size_t)k * 8 + 16 + (may_dense ? (size_t)N * 4 : 0);
     const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(nq, (int64_t)(((size_t)1 << 30) / per_q)));
     const size_t s_pq = align_up((size_t)batch * h->n_nodes * 8, 256), s_keys = align_up((size_t)batch * cap * 8, 256),
                  s_q = q_host ? align_up((size_t)batch * h->dpad * 4, 256) : 0,
+                 s_q16 = q_host && may_dense ? align_up((size_t)batch * h->dpad * 2, 256) : 0,
+                 s_qf = align_up((size_t)batch * 4, 256),
                  s_cand = align_up((size_t)batch * cap * 4, 256),
                  s_bm = bm_lds ? 0 : align_up((size_t)batch * bm_words * 4, 256),
-                 s_ids = align_up((size_t)batch * k * 4, 256), s_cnt = align_up((size_t)batch * 4, 256);
-    MORNA_TRY(h->ws.alloc(s_pq + s_keys + s_q + s_cand + s_bm + 2 * s_ids + s_cnt));
+                 s_ids = align_up((size_t)batch * k * 4, 256),
+                 s_scores = may_dense ? align_up((size_t)batch * N * 4, 256) : 0;
+    MORNA_TRY(h->ws.alloc(s_pq + s_keys + s_q + s_q16 + 6 * s_qf + 2 * s_cand + s_bm + 2 * s_ids + s_scores));
     MORNA_TRY(h->d_stat.alloc(4));
-    // candidate filter on the fp16 rows (MORNA_QUERY_FILTER=0: every candidate gets the fp32 dot); pays when a
-    // query has many more candidates than results
-    static const bool filter_on = !(getenv("MORNA_QUERY_FILTER") && atoi(getenv("MORNA_QUERY_FILTER")) == 0);
-    const bool use_filter = filter_on && cap > 4 * (int64_t)k;
     if (use_filter) MORNA_TRY(split_mm_prepare_rows(h, h->stream));
     DevBuf<int32_t> d_items;
     if (items_host) MORNA_TRY(d_items.alloc((size_t)batch));
 
     for (int64_t q0 = 0; q0 < nq; q0 += batch) {
         const int64_t nb = std::min(batch, nq - q0);
+        const bool dense = may_dense && dense_pays(nb);
         uint8_t *p = h->ws.p;
         QueryParams P;
         P.X = h->X.p; P.norm2 = h->norm2.p; P.n_items = N; P.dpad = h->dpad; P.n_trees = h->n_trees; P.K = h->K;
@@ -328,20 +457,31 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
         P.pq = (uint64_t *)p; p += s_pq;
         P.keys = (uint64_t *)p; p += s_keys;
         float *Qd = (float *)p; p += s_q;
+        _Float16 *Q16 = (_Float16 *)p; p += s_q16;
+        P.qpp = (float *)p; p += s_qf;
+        float *q_n16 = (float *)p; p += s_qf;
+        float *q_e16 = (float *)p; p += s_qf;
+        float *q_scale = (float *)p; p += s_qf;
+        P.ncand = (int32_t *)p; p += s_qf;
+        P.count_out = (int32_t *)p; p += s_qf;
         P.cand = (int32_t *)p; p += s_cand;
+        P.low = (float *)p; p += s_cand;
         P.bm_global = (uint32_t *)p; p += s_bm;
         P.ids_out = (int32_t *)p; p += s_ids;
         P.dist_out = (float *)p; p += s_ids;
-        P.count_out = (int32_t *)p; p += s_cnt;
+        float *scores = (float *)p; p += s_scores;
         P.stat = h->d_stat.p;
-        P.X16 = nullptr; P.xscale = nullptr; P.delta = 0.f;
+        P.X16 = nullptr; P.xscale = nullptr; P.xn16 = P.xe16 = nullptr; P.delta = 0.f;
+        P.scores = nullptr; P.qscale = P.qn16 = P.qe16 = nullptr; P.eacc = 0.f;
         if (use_filter) {
+            const float *xn = (const float *)h->scratch[20].p;
             P.X16 = (const _Float16 *)h->scratch[19].p;
-            P.xscale = (const float *)h->scratch[20].p + N;
-            // |cos from the fp16 row - cos from the fp32 row| <= 2^-11 (one rounding to 11 bits, the query is not
-            // rounded) + the fp32 accumulations of both dots (any order: < dpad * 2^-24 each); the distance is
+            P.xn16 = xn; P.xscale = xn + N; P.xe16 = xn + 2 * N;
+            // gather form: |cos from the fp16 row - cos from the fp32 row| <= 2^-11 (one rounding to 11 bits, the query
+            // is not rounded) + the fp32 accumulations of both dots (any order: < dpad * 2^-24 each); the distance is
             // 2 - 2 cos; 1e-5 covers the evaluation of ang_dist itself
             P.delta = 2.f * (1.02f * 0.00048828125f + 2.f * (float)h->dpad * 5.9604645e-8f) + 1e-5f;
+            P.eacc = mm16_eacc(h->dpad);
         }
         P.Q = nullptr; P.items = nullptr;
         if (q_host) {
@@ -357,23 +497,123 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
             // algorithmic bytes = 4*D*(hyperplane dots + unique candidates + 1) per
             // query; the kernel counts them into d_stat[0], resolve_timers() prices them
             ScopedTimer tm(h, MORNA_T_QUERY, 0);
+            if (dense) {
+                // the contraction does not depend on the traversal: it is enqueued first and the traversal (a latency
+                // chain on few waves) runs beside it on the side stream
+                const _Float16 *q16 = P.X16;
+                const int32_t *qrow = P.items;
+                if (q_host) {
+                    split_mm_convert_rows(h, Qd, nb, Q16, q_n16, q_e16, q_scale, h->stream);
+                    q16 = Q16; qrow = nullptr;
+                    P.qn16 = q_n16; P.qe16 = q_e16; P.qscale = q_scale;
+                } else {
+                    P.qn16 = P.xn16; P.qe16 = P.xe16; P.qscale = P.xscale;
+                }
+                const unsigned n_rt = (unsigned)((N + MM16_TILE - 1) / MM16_TILE), n_ct = (unsigned)((nb + MM16_TILE - 1) / MM16_TILE);
+                HIP_TRY(hipFuncSetAttribute((const void *)query_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MM16_LDS));
+                hipLaunchKernelGGL(query_scores_kernel, dim3(8u * ((n_rt + 7) / 8) * n_ct), dim3(MM16_THREADS), MM16_LDS, h->stream,
+                                   P.X16, N, h->dpad, q16, qrow, (int32_t)nb, scores);
+                P.scores = scores;
+            }
             if (bm_lds) {
                 if (lds > 48 * 1024)   // query image + sample bitmap can pass the default dynamic-LDS limit
-                    HIP_TRY(hipFuncSetAttribute((const void *)query_kernel<true>,
+                    HIP_TRY(hipFuncSetAttribute((const void *)query_traverse_kernel<true>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(query_kernel<true>, dim3((unsigned)nb), dim3(Q_THREADS), lds, h->stream, P);
+                hipLaunchKernelGGL(query_traverse_kernel<true>, dim3((unsigned)nb), dim3(Q_THREADS), lds, h->stream, P);
             } else {
-                hipLaunchKernelGGL(query_kernel<false>, dim3((unsigned)nb), dim3(Q_THREADS), lds, h->stream, P);
+                hipLaunchKernelGGL(query_traverse_kernel<false>, dim3((unsigned)nb), dim3(Q_THREADS), lds_q, h->stream, P);
             }
+#define REFINE(MODE)                                                                                                         \
+    do {                                                                                                                     \
+        if (lds_q > 48 * 1024)                                                                                               \
+            HIP_TRY(hipFuncSetAttribute((const void *)query_refine_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        (int)lds_q));                                                                        \
+        hipLaunchKernelGGL(query_refine_kernel<MODE>, dim3((unsigned)nb), dim3(Q_THREADS), lds_q, h->stream, P);             \
+    } while (0)
+            if (!use_filter) REFINE(0);
+            else if (!dense) REFINE(1);
+            else REFINE(2);
+#undef REFINE
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(ids_out + q0 * k, P.ids_out, (size_t)nb * k * 4, hipMemcpyDeviceToHost, h->stream));
+        if (packed_dev) {
+            // row-sharded search: the answers stay in HBM, packed as the message of the top-k all-gather
+            hipLaunchKernelGGL(pack_topk_kernel, dim3((unsigned)((nb * k + 255) / 256)), dim3(256), 0, h->stream, P.ids_out,
+                               P.dist_out, nb * k, k, (int32_t)id_offset, packed_dev + q0 * 2 * k);
+            HIP_TRY(hipGetLastError());
+        }
+        if (ids_out) HIP_TRY(hipMemcpyAsync(ids_out + q0 * k, P.ids_out, (size_t)nb * k * 4, hipMemcpyDeviceToHost, h->stream));
         if (dist_out)
             HIP_TRY(hipMemcpyAsync(dist_out + q0 * k, P.dist_out, (size_t)nb * k * 4, hipMemcpyDeviceToHost, h->stream));
         if (count_out)
             HIP_TRY(hipMemcpyAsync(count_out + q0, P.count_out, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
+    return MORNA_OK;
+}
+
+// ---- row-sharded search: merge of the all-gathered per-shard answers on the device ----------------------------
+// gathered[world][nq][2 kk] int32: kk global ids (-1 = empty slot, always last) then the kk fp32 distances' bits, each
+// list ascending by (distance, id) as the refine kernel leaves it.  One thread per query walks the `world` list heads.
+__global__ __launch_bounds__(256) void merge_topk_kernel(const int32_t *__restrict__ gathered, int32_t world, int64_t nq,
+                                                         int32_t kk, int32_t k, int32_t *__restrict__ ids_out,
+                                                         float *__restrict__ dist_out, int32_t *__restrict__ count_out)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    constexpr int MAXW = 64;
+    uint8_t head[MAXW];   // kk <= 255 checked by the host
+    for (int w = 0; w < world; w++) head[w] = 0;
+    int n = 0;
+    for (; n < k; n++) {
+        int best = -1;
+        uint32_t bk = 0;
+        int32_t bi = 0;
+        for (int w = 0; w < world; w++) {
+            if (head[w] >= kk) continue;
+            const int32_t *lst = gathered + ((int64_t)w * nq + q) * 2 * kk;
+            const int32_t id = lst[head[w]];
+            if (id < 0) continue;   // the rest of this shard's list is empty
+            const uint32_t dk = f32_orderable(__int_as_float(lst[kk + head[w]]));
+            if (best < 0 || dk < bk || (dk == bk && id < bi)) {
+                best = w;
+                bk = dk;
+                bi = id;
+            }
+        }
+        if (best < 0) break;
+        const int32_t *lst = gathered + ((int64_t)best * nq + q) * 2 * kk;
+        ids_out[q * k + n] = lst[head[best]];
+        dist_out[q * k + n] = __int_as_float(lst[kk + head[best]]);
+        head[best]++;
+    }
+    count_out[q] = n;
+    for (; n < k; n++) {
+        ids_out[q * k + n] = -1;
+        dist_out[q * k + n] = INFINITY;
+    }
+}
+
+int merge_topk_dev(morna_index *h, const int32_t *gathered_dev, int32_t world, int64_t nq, int32_t kk, int32_t k,
+                   int32_t *ids_out, float *dist_out, int32_t *count_out)
+{
+    if (world <= 0 || world > 64 || nq < 0 || kk <= 0 || kk > 255 || k <= 0 || !gathered_dev || !ids_out) {
+        set_error("merge_topk_dev: invalid argument (world <= 64, kk <= 255)");
+        return MORNA_E_INVALID;
+    }
+    if (nq == 0) return MORNA_OK;
+    const size_t s_ids = align_up((size_t)nq * k * 4, 256), s_cnt = align_up((size_t)nq * 4, 256);
+    MORNA_TRY(h->ws.alloc(2 * s_ids + s_cnt));
+    int32_t *d_ids = (int32_t *)h->ws.p;
+    float *d_dist = (float *)(h->ws.p + s_ids);
+    int32_t *d_cnt = (int32_t *)(h->ws.p + 2 * s_ids);
+    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->stream, gathered_dev, world, nq, kk,
+                       k, d_ids, d_dist, d_cnt);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(ids_out, d_ids, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
+    if (dist_out) HIP_TRY(hipMemcpyAsync(dist_out, d_dist, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
+    if (count_out) HIP_TRY(hipMemcpyAsync(count_out, d_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return MORNA_OK;
 }
 

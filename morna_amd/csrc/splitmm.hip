@@ -25,13 +25,14 @@
 
 #include "common.hpp"
 #include "devutil.hpp"
+#include "mm16.hpp"
 
 namespace morna {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static inline float sm_eps(int32_t dpad) { return (2.f * (float)dpad + 2.f) * 5.9604645e-8f + 4.1e-6f; }   // EACC
+static inline float sm_eps(int32_t dpad) { return mm16_eacc(dpad); }   // EACC
 
 // ---- fp16 image of a row-major fp32 matrix: one wave per row ---------------------------------------
 // dst row = fp16(2^e * src row) with max |2^e x_i| in [2^14, 2^15); norm[row] = an upper bound of the
@@ -120,35 +121,6 @@ __global__ __launch_bounds__(SM_THREADS) void split_mm_kernel(
     const int c0 = (int)((blockIdx.x >> 3) % n_ct) * SM_TILE;
     if (r0 >= n_items) return;
 
-    // Operand slabs go from global memory straight into LDS (global_load_lds_dwordx4: no staging registers, no
-    // ds_write -- the VGPR -> LDS store path, ~80 B/clk, would take as long as the slab's MFMAs).  One wave
-    // instruction fills 1 KiB of LDS = 8 tile rows of 128 B, lane i at byte 16 i.  The image is unpadded, so the
-    // 16-byte chunks of row r are XOR-swizzled with (r >> 1) & 7: lane i fetches chunk (i & 7) ^ f(row) of its
-    // row, a reader finds chunk c of row r at position c ^ f(r), and the 16 lanes ds_read_b128 serves per cycle
-    // (rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of a 32-row fragment) fall on 16 different bank groups.
-    // Two buffers: the slab of step k+1 lands while step k is multiplied; one barrier per step.
-    auto dma = [&](int k0, int buf) {
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int j = w * 4 + u;                       // 32 instructions per step: 16 for the rows, 16 for the hyperplanes
-            const bool is_x = j < 16;
-            const int rt = ((is_x ? j : j - 16) << 3) + (lane >> 3);   // row of the tile
-            const int chunk = (lane & 7) ^ ((rt >> 1) & 7);
-            // rows past the end repeat the last one: their products are never looked up
-            const int64_t gx = r0 + rt < n_items ? r0 + rt : n_items - 1;
-            const int64_t gh = c0 + rt < n_tasks ? c0 + rt : n_tasks - 1;
-            const _Float16 *src = (is_x ? X16 + gx * dpad : H16 + gh * dpad) + k0 + chunk * 8;
-            unsigned char *dst = smem + buf * (2 * SM_TILE * SM_BK * 2) + (is_x ? 0 : SM_TILE * SM_BK * 2) +
-                                 (is_x ? j : j - 16) * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-        }
-    };
-    f32x16 acc[2], acc_odd[2];   // even / odd K-steps: two shorter accumulation chains (the bound above)
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[j][e] = acc_odd[j][e] = 0.f;
     if (tid < SM_TILE) {
         const int col = c0 + tid < n_tasks ? c0 + tid : n_tasks - 1;
         const SplitTask t = tasks[col];
@@ -159,41 +131,14 @@ __global__ __launch_bounds__(SM_THREADS) void split_mm_kernel(
         s_hn[tid] = hn[col];
         s_he[tid] = he[col];
     }
-
-    dma(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // the contraction (mm16.hpp): hyperplanes are the A side (m) and the rows the B side (n), so the result has a
+    // row of X on the lane and the epilogue's look-ups and side bytes of a wave run along consecutive rows; rows
+    // past the end repeat the last one: their products are never looked up
+    f32x16 acc[2];
+    mm16_tile(X16, H16, dpad, smem,
+              [&](int rt) { return r0 + rt < n_items ? r0 + rt : n_items - 1; },
+              [&](int rt) { return (int64_t)(c0 + rt < n_tasks ? c0 + rt : n_tasks - 1); }, acc);
     const int lr = lane & 31, lh = lane >> 5;
-    const int xrow = wm * 32 + lr, xsw = (xrow >> 1) & 7;
-    auto kstep = [&](int k0, int buf, f32x16(&ac)[2]) {
-        if (k0 + SM_BK < dpad) dma(k0 + SM_BK, buf ^ 1);   // next slab lands in the other buffer under the MFMAs
-        const unsigned char *xs = smem + buf * (2 * SM_TILE * SM_BK * 2);
-        const unsigned char *hs = xs + SM_TILE * SM_BK * 2;
-#pragma unroll
-        for (int blk = 0; blk < SM_BK / 16; blk++) {
-            // 32x32x16: lane (r = l & 31, h = l >> 5) supplies A[m = r][k = 8h + j], B[k = 8h + j][n = r], j = 0..7,
-            // i.e. the 16-byte chunk 2 blk + h of its row.  The HYPERPLANES are the A side (m) and the rows the B
-            // side (n): the result then has a row of X on the lane, so the epilogue's look-ups and side bytes of a
-            // wave run along consecutive rows.
-            const int kc = 2 * blk + lh;
-            const f16x8 x8 = *(const f16x8 *)(xs + xrow * 128 + ((kc ^ xsw) << 4));
-#pragma unroll
-            for (int tn = 0; tn < 2; tn++) {
-                const int hrow = wn * 64 + tn * 32 + lr;
-                const f16x8 h8 = *(const f16x8 *)(hs + hrow * 128 + ((kc ^ ((hrow >> 1) & 7)) << 4));
-                ac[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8, x8, ac[tn], 0, 0, 0);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the next slab is in LDS
-        __syncthreads();
-    };
-    // dpad is a multiple of 256: an even number of K-steps; the buffer index is the step's parity
-    for (int k0 = 0; k0 < dpad; k0 += 2 * SM_BK) {
-        kstep(k0, 0, acc);
-        kstep(k0 + SM_BK, 1, acc_odd);
-    }
-#pragma unroll
-    for (int tn = 0; tn < 2; tn++) acc[tn] = acc[tn] + acc_odd[tn];
 
     // The result goes to LDS as C[hyperplane][row].  C/D layout of the 32x32 MFMA: n = lane & 31 (a row of X),
     // m = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (a hyperplane = a task of the level).
@@ -322,6 +267,17 @@ int split_mm_prepare_rows(morna_index *h, hipStream_t stream)
                        h->n_items, h->dpad, x16.p, xn.p, xn.p + 2 * h->n_items, xn.p + h->n_items, (unsigned int *)nullptr);
     HIP_TRY(hipGetLastError());
     h->half_valid = true;
+    return MORNA_OK;
+}
+
+// fp16 image of any row-major fp32 matrix with the library's row stride (the query vectors of a batch, knn.hip):
+// dst[rows][dpad], per row an upper bound of the image's norm, of its rounding error's norm, and 2^-e
+int split_mm_convert_rows(morna_index *h, const float *src, int64_t rows, _Float16 *dst, float *norm, float *err,
+                          float *inv_scale, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rows_to_half_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, src, rows, h->dpad, dst,
+                       norm, err, inv_scale, (unsigned int *)nullptr);
+    HIP_TRY(hipGetLastError());
     return MORNA_OK;
 }
 

@@ -110,9 +110,29 @@ class ShardedSearch(object):
             all_d = self._all_gather_np(np.ascontiguousarray(d, np.float32))
         return merge_topk_native(all_ids, all_d, k)
 
+    def _device_path(self):
+        """RCCL group and a shard that can keep its answers in HBM (libmorna_hip's packed entry points)."""
+        return (self.device.type == "cuda" and hasattr(self.index, "get_nns_by_vector_packed")
+                and self.n_total < 2 ** 31 and self.world <= 64)
+
+    def _search_gather_merge_dev(self, q_ptr, nq, k, search_k):
+        """The data path of SURVEY.md 8(e) without a host hop: per-shard top-k written to HBM as one [nq, 2k] int32
+        message (global ids, distance bits), RCCL all-gather of Q*k*8 bytes per rank, merge kernel; only the merged
+        result crosses PCIe."""
+        packed = torch.empty((nq, 2 * k), dtype=torch.int32, device=self.device)
+        self.index.get_nns_by_vector_packed(q_ptr, nq, k, search_k, int(self.offsets[self.rank]), packed.data_ptr())
+        gathered = torch.empty((self.world, nq, 2 * k), dtype=torch.int32, device=self.device)
+        dist.all_gather_into_tensor(gathered, packed, group=self.group)
+        torch.cuda.current_stream().synchronize()                 # the library merges on its own stream
+        ids, d, cnt = self.index.merge_topk_packed(gathered.data_ptr(), self.world, nq, k, k)
+        return ids.astype(np.int64), d, cnt
+
     def get_nns_by_vector(self, Q, k, search_k=-1):
         """Q: [nq, f] fp32, identical on every rank.  Returns merged global ids,
         distances and counts on every rank."""
+        if self._device_path() and k <= 255:
+            Q = np.ascontiguousarray(Q, dtype=np.float32)
+            return self._search_gather_merge_dev(Q.ctypes.data, Q.shape[0], k, search_k)
         ids, d, cnt = self.index.get_nns_by_vector_batch(Q, k, search_k)
         return self._gather_merge(ids, d, k)
 
@@ -148,6 +168,8 @@ class ShardedSearch(object):
             dist.all_gather(outs, mine, group=self.group)                       # query vectors: nq * D * 4 bytes, once
             Q = torch.cat([outs[g][:n_each[g]] for g in range(self.world)], dim=0).contiguous()
             torch.cuda.current_stream().synchronize()                          # the library reads Q on its own stream
+            if self._device_path() and k <= 255:
+                return self._search_gather_merge_dev(Q.data_ptr(), Q.shape[0], k, search_k)
             ids, d, cnt = self.index.get_nns_by_vector_ptr(Q.data_ptr(), Q.shape[0], k, search_k)
             return self._gather_merge(ids, d, k)
         mine = np.zeros((n_max, f), np.float32)

@@ -1,0 +1,138 @@
+"""Row-sharded search with REAL shards (libmorna_hip indexes), -m gpu.
+
+The 8-GPU run is the driver's; what can be checked on one GPU:
+  * two ranks (two processes sharing the device, gloo between them -- RCCL refuses two ranks on one GPU), each holding
+    a ragged shard with its own forest, against one index over the union of the rows: exact search identical
+    (ids, fp64 distances, the bisect_left tie rule across shards); approximate search equal to the merge of the two
+    shards' own answers, and not worse in recall than the single index;
+  * the device-resident exchange of the RCCL path (answers packed in HBM -> all-gather -> merge kernel) against the
+    host merge, with ties across shards, short lists and empty slots; the 1-rank RCCL group runs it end to end in
+    test_gpu_parity.py / test_gpu_configs.py.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+F, T, K = 96, 10, 12
+BOUNDS = [0, 2300, 5000]
+
+
+def _rows():
+    rng = np.random.default_rng(77)
+    C = rng.standard_normal((30, F)).astype(np.float32)
+    X = (C[rng.integers(0, 30, BOUNDS[-1])] + 0.5 * rng.standard_normal((BOUNDS[-1], F))).astype(np.float32)
+    X[4000] = X[10]                     # the same row on both shards: equal distances across the shard boundary
+    X[4001] = X[10] * np.float32(2.0)
+    return X
+
+
+def _worker(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    from morna_amd.annoy import AnnoyIndex
+    from morna_amd.dist import ShardedSearch, merge_topk
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X = _rows()
+        shards = []
+        for g in range(world):          # every rank builds both shards (builds are deterministic): rank g SERVES shard g
+            a = AnnoyIndex(F)
+            a.add_items(X[BOUNDS[g]:BOUNDS[g + 1]])
+            a.build(T)
+            shards.append(a)
+        whole = AnnoyIndex(F)
+        whole.add_items(X)
+        whole.build(T)
+        ss = ShardedSearch(shards[rank], rank, world, BOUNDS[rank + 1] - BOUNDS[rank])
+        assert ss.offsets.tolist() == BOUNDS
+        rng = np.random.default_rng(3)
+        Q = X[rng.choice(BOUNDS[-1], 40, replace=False)] + 0.01 * rng.standard_normal((40, F)).astype(np.float32)
+        Q[0] = X[10]
+        # exact: the row-sharded scan IS the single scan
+        eids, ed, ecnt = ss.exact_search(Q.astype(np.float64), K)
+        wids, wd, wcnt = whole.exact_search_batch(Q.astype(np.float64), K)
+        assert eids.tolist() == wids.astype(np.int64).tolist() and ed.tobytes() == wd.tobytes()
+        assert ecnt.tolist() == wcnt.tolist()
+        assert eids[0, :2].tolist() == [4000, 10]       # equal distance: the higher global id first (bisect_left)
+        # approximate: what the collective returns is the merge of the shards' own answers
+        for sk in (-1, 60):
+            ids, d, cnt = ss.get_nns_by_vector(Q, K, sk)
+            per = [s.get_nns_by_vector_batch(Q, K, sk) for s in shards]
+            gi = np.stack([np.where(p[0] >= 0, p[0].astype(np.int64) + BOUNDS[g], -1) for g, p in enumerate(per)])
+            want = merge_topk(gi, np.stack([p[1] for p in per]), K)
+            assert ids.tolist() == want[0].tolist() and np.array_equal(np.asarray(d, np.float32), want[1])
+            assert cnt.tolist() == want[2].tolist()
+        ids, d, cnt = ss.get_nns_by_vector(Q, K, -1)
+        wa = whole.get_nns_by_vector_batch(Q, K, -1)[0]
+        rec_s = np.mean([len(set(ids[i].tolist()) & set(eids[i].tolist())) / float(K) for i in range(len(Q))])
+        rec_w = np.mean([len(set(wa[i].tolist()) & set(eids[i].tolist())) / float(K) for i in range(len(Q))])
+        assert rec_s >= rec_w - 0.02, (rec_s, rec_w)   # two forests inspect at least what one does
+        # by-item: every rank asks about rows of its own shard
+        mine = np.array([10, 11, 12], np.int32) if rank == 0 else np.array([1700, 1701], np.int32)
+        ids2, d2, cnt2 = ss.get_nns_by_local_items(mine, K, -1)
+        gl = [10, 11, 12, BOUNDS[1] + 1700, BOUNDS[1] + 1701]
+        ids3, d3, cnt3 = ss.get_nns_by_vector(X[gl], K, -1)
+        assert ids2.tolist() == ids3.tolist() and np.array_equal(d2, d3)
+        assert [int(ids2[i, 0]) for i in (1, 2, 3, 4)] == gl[1:]        # a row is its own nearest neighbour
+        assert sorted(ids2[0, :2].tolist()) == [10, 4000] and d2[0, 1] < 1e-3
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_real_shards_one_device_gloo():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def test_packed_device_exchange_equals_host_merge():
+    """morna_get_nns_by_vector_packed + morna_merge_topk_packed: three shards' answers packed in HBM, laid out as the
+    all-gather would leave them, merged on the device -- against the host k-way merge of the same answers."""
+    import torch
+    from morna_amd.annoy import AnnoyIndex
+    from morna_amd.dist import merge_topk_native
+    X = _rows()
+    bounds = [0, 7, 2300, 5000]         # the first shard is smaller than k: empty slots in its lists
+    rng = np.random.default_rng(9)
+    Q = np.ascontiguousarray(X[rng.choice(5000, 70, replace=False)])
+    Q[1] = X[10]
+    k = 20
+    shards, host = [], []
+    dev = torch.device("cuda", 0)
+    gathered = torch.empty((3, len(Q), 2 * k), dtype=torch.int32, device=dev)
+    for g in range(3):
+        a = AnnoyIndex(F)
+        a.add_items(X[bounds[g]:bounds[g + 1]])
+        a.build(T)
+        a.get_nns_by_vector_packed(Q.ctypes.data, len(Q), k, -1, bounds[g], gathered[g].data_ptr())
+        ids, d, cnt = a.get_nns_by_vector_batch(Q, k, -1)
+        host.append((np.where(ids >= 0, ids.astype(np.int64) + bounds[g], -1), d))
+        shards.append(a)
+    torch.cuda.synchronize()
+    got = gathered.cpu().numpy()
+    for g in range(3):                  # the message itself: global ids, then the distance bits
+        assert got[g, :, :k].tolist() == host[g][0].tolist()
+        assert got[g, :, k:].view(np.float32).tobytes() == host[g][1].tobytes()
+    ids, d, cnt = shards[2].merge_topk_packed(gathered.data_ptr(), 3, len(Q), k, k)
+    want = merge_topk_native(np.stack([h[0] for h in host]), np.stack([h[1] for h in host]), k)
+    assert ids.astype(np.int64).tolist() == want[0].tolist() and d.tobytes() == want[1].tobytes()
+    assert cnt.tolist() == want[2].tolist()
+    assert sorted(ids[1, :2].tolist()) == [10, 4000]
+    ids5, d5, cnt5 = shards[0].merge_topk_packed(gathered.data_ptr(), 3, len(Q), k, 5)   # k smaller than the lists
+    assert ids5.tolist() == ids[:, :5].tolist() and (cnt5 == 5).all()
+    with pytest.raises(ValueError):
+        shards[0].merge_topk_packed(gathered.data_ptr(), 65, len(Q), k, 5)

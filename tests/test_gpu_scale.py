@@ -234,11 +234,11 @@ def test_filters_do_not_change_results(tmp_path):
         fh.write(_FOREST_DIGEST.format(root=root))
     out = {}
     for name, extra in (("default", {}), ("no_mm", {"MORNA_SPLIT_MM": "0"}), ("no_qf", {"MORNA_QUERY_FILTER": "0"}),
-                        ("no_strip", {"MORNA_TM_STRIP": "0"})):
+                        ("no_strip", {"MORNA_TM_STRIP": "0"}), ("no_dense", {"MORNA_QUERY_DENSE": "0"})):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0].split()
         out[name] = line[1:]
-    assert out["default"] == out["no_mm"] == out["no_qf"] == out["no_strip"], out
+    assert out["default"] == out["no_mm"] == out["no_qf"] == out["no_strip"] == out["no_dense"], out
     assert int(out["default"][2]) >= 4                                      # deep enough for every form to run
