@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--junctions", type=int, default=70_000,
                     help="junction lines; 70k gives nnz ~ 2000 per sample (SURVEY.md 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs[4] shard pass reported beside the headline")
     ap.add_argument("--cpu-trees", type=int, default=24)
     ap.add_argument("--cpu-queries", type=int, default=200)
     ap.add_argument("--verify", action="store_true", help="check results against the exact search")
@@ -106,6 +107,42 @@ def _cpu_baseline_mt(args, capi, X, items, N, D, t_feat, t_dot):
                 sample=("oracle/ on %d threads, one oracle instance and one tree per thread (%.1fs wall), %d queries per "
                         "thread; extrapolated: features %.1fs (sequential) + forest %.1fs + queries %.1fs"
                         % (threads, wall, nq, t_feat, forest, queries)))
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak (MI355X_MICROARCH.md)
+
+
+def exact_all_pairs_shard(args, device):
+    """BASELINE.json configs[4] on one GPU's share: 50k x 8192 exact all-pairs k-NN row-sharded over 8 GPUs = 6250 rows
+    per GPU, every row of the shard a query (morna.py:681-716 per item).  Extra key, never part of `value`: one warm
+    pass, one timed pass; the scan runs on the fp32 matrix cores, so its roof is the fp32 MFMA peak."""
+    from morna_amd.annoy import AnnoyIndex
+    from morna_amd.index import prepare_csr
+    from morna_amd.synth import synthetic_intropolis
+    n, D, k = 6250, 8192, 20
+    data = synthetic_intropolis(n, J=args.junctions)
+    prep = prepare_csr(data["keys"], data["row_ptr"], data["samples"], data["cov"], data["sample_count"], 100)
+    a = AnnoyIndex(D, device=device)
+    a.stage_junctions(prep["key_bytes"], prep["key_off"], prep["row_ptr"], prep["ids"], prep["cov"], prep["idf"])
+    a.build_features(prep["n_items"])
+    a.unstage_junctions()
+    Qd = a.get_items().astype(np.float64)
+    a.exact_search_batch(Qd, k)
+    a.timer_reset()
+    a.timer_enable(True, only=["exact", "exact_scan"])
+    t0 = time.perf_counter()
+    ids, d, cnt = a.exact_search_batch(Qd, k)
+    wall = time.perf_counter() - t0
+    a.timer_enable(False)
+    tm = a.timers()
+    scan = tm["exact_scan"]
+    tfl = scan["bytes"] / 1e12 / (scan["ms"] / 1e3) if scan["ms"] > 0 else 0.0
+    return {"workload": "%d x %d shard of configs[4] (50k x 8192 over 8 GPUs), all %d rows as queries, k=%d" % (n, D, n, k),
+            "wall_ms": 1e3 * wall, "queries_per_sec": n / wall, "scan_ms": scan["ms"], "exact_group_ms": tm["exact"]["ms"],
+            "self_is_nearest": bool((ids[:, 0] == np.arange(n)).all()),
+            "roofline": {"kernel": "exact_scan_mfma_kernel", "bound": "mfma", "achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tfl / MFMA_F32_PEAK_TFLOPS, "flops": scan["bytes"],
+                         "host_copy_note": "wall_ms includes the host <-> device copies of queries and results"}}
 
 
 def cpu_baseline(args, data, prep, items):
@@ -228,10 +265,25 @@ def main():
         torch.cuda.synchronize()
         index.synchronize()
 
-    for _ in range(args.warmup):
+    GROUPS = ("features", "two_means", "split", "query")
+    # Warm-up.  Its last step is bracketed with events on every kernel group to find the group that takes the most
+    # time; the timed region then brackets THAT group only (an event pair costs the stream a few microseconds of idle).
+    dominant = "two_means"
+    for w in range(args.warmup):
+        if w == args.warmup - 1:
+            index.timer_reset()
+            index.timer_enable(True)
         step()
+    if args.warmup > 0:
+        index.timer_enable(False)
+        probe = index.timers()
+        dominant = max(GROUPS, key=lambda n: probe[n]["ms"])
+    if world > 1:   # every rank brackets the same group
+        code = torch.tensor([GROUPS.index(dominant)], dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.broadcast(code, src=0)
+        dominant = GROUPS[int(code.item())]
     index.timer_reset()
-    index.timer_enable(True)
+    index.timer_enable(True, only=[dominant] if os.environ.get("MORNA_BENCH_TIMERS", "dominant") == "dominant" else list(GROUPS))
     fence()
     t_start = time.perf_counter()
     tb = tq = 0.0
@@ -243,39 +295,48 @@ def main():
     fence()
     elapsed = time.perf_counter() - t_start
     index.timer_enable(False)
-    timers = index.timers()
+    timed = index.timers()
     if world > 1:
         t = torch.tensor([elapsed, tb, tq], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, tb, tq = [float(x) for x in t.tolist()]
     st = index.forest_stats()
+    # After the timed region (not part of `value`): the same step with every group bracketed, for the breakdown
+    n_bd = max(1, min(args.steps, 5))
+    index.timer_reset()
+    index.timer_enable(True)
+    for _ in range(n_bd):
+        step()
+    index.timer_enable(False)
+    timers = index.timers()
 
     out = None
     if rank == 0:
         # One roofline entry per kernel group, from the HIP-event timers of the library (events recorded on the
         # stream the kernels run on) and the algorithmic bytes of SURVEY.md 8(d) that the library counts per launch.
         # The split group is priced at one pass over the rows per level (see below), not per (row, split node).
-        kernels_of = {"features": ("morna::accumulate_kernel", "morna::transpose_convert_kernel", "morna::hash_keys_kernel",
-                                   "morna::col_fill_kernel", "morna::line_flags_kernel", "morna::row_norms_kernel"),
+        kernels_of = {"features": ("morna::accumulate", "morna::transpose_convert_kernel", "morna::hash_keys_kernel",
+                                   "morna::col_", "morna::line_", "morna::row_norms_kernel"),
                       "two_means": ("morna::two_means",), "split": ("morna::split_", "morna::rows_to_half", "morna::invert_kernel"),
-                      "partition": ("morna::partition_kernel",), "query": ("morna::query_kernel",)}
+                      "partition": ("morna::partition_kernel",), "query": ("morna::query_",)}
         tj = None
-        tpath = os.path.join(ROOT, "profiles", "r01_c3_traffic.json")
-        if os.path.exists(tpath):
+        import glob
+        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3_traffic.json")), reverse=True):
             with open(tpath) as fh:
-                tj = json.load(fh)
-            cfg = tj.get("config", {})
-            if (cfg.get("samples"), cfg.get("features"), cfg.get("trees")) != (N, D, T):
-                tj = None   # HBM-side bytes are only quoted for the workload they were measured on
+                cand = json.load(fh)
+            cfg = cand.get("config", {})
+            if (cfg.get("samples"), cfg.get("features"), cfg.get("trees")) == (N, D, T):
+                tj, tj_name = cand, os.path.relpath(tpath, ROOT)   # HBM-side bytes are only quoted for the workload they were measured on
+                break
 
-        def group(name):
-            tm = timers[name]
+        def group(name, tms, n_steps):
+            tm = tms[name]
             if tm["ms"] <= 0:
                 return None
             launches = max(tm["launches"], 1)
             gbs = (tm["bytes"] / 1e9) / (tm["ms"] / 1e3)
             g = {"kernel": name, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": gbs / HBM_PEAK_GBS, "launches": tm["launches"] // max(args.steps, 1),
+                 "frac": gbs / HBM_PEAK_GBS, "launches": tm["launches"] // max(n_steps, 1),
                  "alg_bytes_per_launch": tm["bytes"] // launches, "ms_per_launch": tm["ms"] / launches,
                  "traffic": None}
             if name == "split":
@@ -288,30 +349,51 @@ def main():
                 levels = max(tm["launches"], 1)
                 rows_per_level = float(n_items)        # every row is in a split node of every tree at these levels
                 min_bytes = (4.0 * dpad_of(D) * rows_per_level + float(n_items) * T) * levels \
-                    + 4.0 * dpad_of(D) * st["n_split"] * args.steps
+                    + 4.0 * dpad_of(D) * st["n_split"] * n_steps
                 gbs = min_bytes / 1e9 / (tm["ms"] / 1e3)
-                flops = 2.0 * D * (st["split_rows"] + st["n_split"]) * args.steps      # one dot per row and split node
-                executed = 2.0 * n_items * st["n_split"] * D * args.steps             # every row x every hyperplane of its level
+                flops = 2.0 * D * (st["split_rows"] + st["n_split"]) * n_steps      # one dot per row and split node
+                executed = 2.0 * n_items * st["n_split"] * D * n_steps             # every row x every hyperplane of its level
                 g.update(achieved=gbs, frac=gbs / HBM_PEAK_GBS, alg_bytes_per_launch=int(min_bytes / levels),
                          alg_bytes_per_launch_no_reuse=tm["bytes"] // launches,
                          mfma_floor={"algorithmic_tflops": flops / 1e12 / (tm["ms"] / 1e3), "peak": MFMA_F16_PEAK_TFLOPS,
                                      "executed_tflops": executed / 1e12 / (tm["ms"] / 1e3)})
+            if name == "query":
+                # SURVEY.md 8(d) prices a query at 4*D bytes per hyperplane dot and per candidate row (27 GB per 1000
+                # queries here).  The candidate filter no longer gathers candidate rows: one contraction of all
+                # queries against the whole fp16 image reads the matrix ONCE, so the group's longest kernel is bound
+                # by the matrix cores, and that is the roof quoted.  Beside it: the bytes the group is defined to move
+                # (fp16 matrix once + scores out and back in for the candidates + hyperplanes of the traversal + fp32
+                # rows of the survivors, ~2k per query) against the HBM peak.
+                f = tms.get("query_filter", {"ms": 0, "bytes": 0})
+                if f["ms"] > 0:
+                    tfl = f["bytes"] / 1e12 / (f["ms"] / 1e3)
+                    cand_rows = tm["bytes"] / (4.0 * D)            # hyperplane dots + candidates + 1, all queries, all steps
+                    defined = n_steps * (2.0 * dpad_of(D) * n_items + 4.0 * Q * n_items) + 4.0 * cand_rows \
+                        + n_steps * Q * 4.0 * dpad_of(D) * (T + 8 + 2 * k + 1)
+                    g.update(bound="mfma", achieved=tfl, peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s", frac=tfl / MFMA_F16_PEAK_TFLOPS,
+                             ms_per_launch=f["ms"] / max(f["launches"], 1), flops_per_launch=f["bytes"] // max(f["launches"], 1),
+                             group_ms_per_launch=tm["ms"] / launches,
+                             hbm={"defined_bytes_per_launch": int(defined / launches), "achieved": defined / 1e9 / (tm["ms"] / 1e3),
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": defined / 1e9 / (tm["ms"] / 1e3) / HBM_PEAK_GBS,
+                                  "survey_8d_bytes_per_launch": tm["bytes"] // launches})
+                    del g["alg_bytes_per_launch"]
             if tj:
-                ks = [v for k, v in tj["kernels"].items() if k.startswith(kernels_of[name])]
+                ks = [v for kk, v in tj["kernels"].items() if kk.startswith(kernels_of[name])]
                 if ks:   # bytes past L2 per timed launch group, from separate rocprofv3 --pmc passes
-                    g["traffic"] = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in ks) / max(tm["launches"] // max(args.steps, 1), 1)
-                    g["traffic_source"] = "profiles/r01_c3_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+                    g["traffic"] = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in ks) / max(tm["launches"] // max(n_steps, 1), 1)
+                    g["traffic_source"] = tj_name + " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+            if g["frac"] > 1.0:
+                raise SystemExit("bench.py: roofline fraction %.2f > 1 for %s -- the bytes or the peak are wrong" % (g["frac"], name))
             return g
-        groups = {n: group(n) for n in ("features", "two_means", "split", "query")}
+        groups = {n: group(n, timers, n_bd) for n in GROUPS}
         groups = {n: g for n, g in groups.items() if g}
-        dominant = max(groups, key=lambda n: timers[n]["ms"])
         notes = {"two_means": "one chain of 200 dependent steps per split node (annoy's two_means): bound by the latency of "
-                              "that chain at shallow levels and by VALU issue at deep ones; its rows are gathered at random",
+                              "that chain at shallow levels and by the random-row gather from HBM at deep ones",
                  "split": "a level's sides as one fp16 MFMA contraction that filters + exact fp32 dots for the ~0.5% it leaves open; "
                           "bytes = one pass over the fp32 rows per level + hyperplanes + side bytes (rows reused across trees on chip)",
                  "features": "fp64 accumulation in file order in LDS tiles; the nnz stream is read once per sample tile",
-                 "query": "candidate rows gathered at random: fp16 filter pass, fp32 for the survivors"}
-        roofline = dict(groups[dominant], note=notes[dominant])
+                 "query": "traversal || whole-batch fp16 filter contraction on the matrix cores, then fp32 dots for the survivors"}
+        roofline = dict(group(dominant, timed, args.steps), note=notes[dominant], measured="HIP events in the timed region")
         total_samples = n_items * world * args.steps
         out = {
             "metric": "samples indexed/sec (index build + %d queries, k=%d) at %dk x %d" % (Q, k, N // 1000, D),
@@ -332,7 +414,8 @@ def main():
             "stage_ms": 1e3 * t_stage,
             "samples_per_sec_pcie_inclusive": n_items * world / (elapsed / args.steps + t_stage),
             "build_ms_per_step": 1e3 * tb / args.steps, "query_ms_per_step": 1e3 * tq / args.steps,
-            "kernel_ms_per_step": {n: round(v["ms"] / args.steps, 3) for n, v in timers.items()},
+            # breakdown: %d extra steps AFTER the timed region, every group bracketed with events
+            "kernel_ms_per_step": {n: round(v["ms"] / n_bd, 3) for n, v in timers.items()},
             "forest": {"n_nodes": st["n_nodes"], "n_split": st["n_split"], "max_depth": st["max_depth"],
                        "split_rows": st["split_rows"], "split_attempts": st["split_attempts"],
                        "fallback_nodes": st["fallback_nodes"]},
@@ -344,6 +427,8 @@ def main():
             eids, _, _ = index.exact_search_batch(index.get_items()[items[:64]].astype(np.float64), k)
             rec = np.mean([len(set(ids[i].tolist()) & set(eids[i].tolist())) / float(k) for i in range(len(eids))])
             out["recall_at_k_vs_exact"] = float(rec)
+        if world == 1 and not args.no_extras:
+            out["exact_all_pairs_shard"] = exact_all_pairs_shard(args, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             prep["X_host"] = index.get_items()
             out["cpu_baseline"] = cpu_baseline(args, data, prep, items)

@@ -197,9 +197,12 @@ enum {
     MORNA_T_PARTITION = 3,  /* forest: stable partition                        */
     MORNA_T_QUERY = 4,      /* traversal + refine + top-k                      */
     MORNA_T_EXACT = 5,      /* exact scan + re-rank                            */
-    MORNA_T_COUNT = 6
+    MORNA_T_QUERY_FILTER = 6, /* part of MORNA_T_QUERY: the whole-batch fp16 contraction (bytes = its flops) */
+    MORNA_T_EXACT_SCAN = 7, /* part of MORNA_T_EXACT: the fp32 scan (bytes = its flops when it ran on the matrix cores) */
+    MORNA_T_COUNT = 8
 };
-/* HIP-event timing of the kernels on the handle's own stream */
+/* HIP-event timing of the kernels on the handle's own stream.  on: 0 off, 1 every group, otherwise a mask with bit
+ * (MORNA_T_x + 1) set for each group to time (each event pair costs the stream a few microseconds of idle) */
 int morna_timer_enable(morna_index *h, int32_t on);
 int morna_timer_reset(morna_index *h);
 /* ms = summed event time, launches, bytes = algorithmic bytes of those launches */

@@ -11,8 +11,8 @@ LIB_PATH = os.path.join(_HERE, "libmorna_hip.so")
 
 OK, E_INVALID, E_HIP, E_STATE, E_RANGE, E_IO, E_EMPTY = 0, -1, -2, -3, -4, -5, -6
 
-T_FEATURES, T_TWO_MEANS, T_SPLIT, T_PARTITION, T_QUERY, T_EXACT = range(6)
-TIMER_NAMES = ["features", "two_means", "split", "partition", "query", "exact"]
+T_FEATURES, T_TWO_MEANS, T_SPLIT, T_PARTITION, T_QUERY, T_EXACT, T_QUERY_FILTER, T_EXACT_SCAN = range(8)
+TIMER_NAMES = ["features", "two_means", "split", "partition", "query", "exact", "query_filter", "exact_scan"]
 
 
 class ForestStats(C.Structure):

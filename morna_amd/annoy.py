@@ -218,8 +218,10 @@ class AnnoyIndex(object):
         return True
 
     # ---- measurement -----------------------------------------------------------
-    def timer_enable(self, on=True):
-        check(lib().morna_timer_enable(self._h, 1 if on else 0))
+    def timer_enable(self, on=True, only=None):
+        """only: names of the kernel groups to bracket with events (default: all of them)."""
+        mask = (1 if on else 0) if only is None else sum(2 << _lib.TIMER_NAMES.index(n) for n in only)
+        check(lib().morna_timer_enable(self._h, mask))
 
     def timer_reset(self):
         check(lib().morna_timer_reset(self._h))

@@ -681,6 +681,9 @@ int morna_timer_enable(morna_index *h, int32_t on)
     CHECK_H(h);
     if (!on) resolve_timers(h);
     h->timing = on != 0;
+    // 1: every group; otherwise bit (which + 1) selects group `which` (an event pair costs the stream a few
+    // microseconds of idle, so a benchmark brackets only the group it prices)
+    h->timing_mask = on == 1 ? 0xffffffffu : ((uint32_t)on >> 1);
     return MORNA_OK;
 }
 

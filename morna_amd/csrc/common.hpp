@@ -167,6 +167,7 @@ struct morna_index {
 
     // timing
     bool timing = false;
+    uint32_t timing_mask = 0;          // bit `which` set: that kernel group is bracketed by events
     morna::Timer timers[MORNA_T_COUNT];
     std::vector<morna::PendingEv> pending_ev;  // resolved by resolve_timers()
     std::vector<hipEvent_t> free_ev;
@@ -186,14 +187,14 @@ struct ScopedTimer {
         pe.which = which;
         pe.bytes = bytes;
         pe.a = pe.b = nullptr;
-        if (!h->timing) return;
+        if (!h->timing || !(h->timing_mask & (1u << which))) return;
         pe.a = take_event(h);
         pe.b = take_event(h);
         (void)hipEventRecord(pe.a, h->stream);
     }
     ~ScopedTimer()
     {
-        if (!h->timing) return;
+        if (!pe.a) return;
         (void)hipEventRecord(pe.b, h->stream);
         h->pending_ev.push_back(pe);
     }

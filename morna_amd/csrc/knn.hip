@@ -498,8 +498,8 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
             // query; the kernel counts them into d_stat[0], resolve_timers() prices them
             ScopedTimer tm(h, MORNA_T_QUERY, 0);
             if (dense) {
-                // the contraction does not depend on the traversal: it is enqueued first and the traversal (a latency
-                // chain on few waves) runs beside it on the side stream
+                HIP_TRY(hipEventRecord(h->ev_fork, h->stream));   // the query vectors / item ids are in place
+                HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
                 const _Float16 *q16 = P.X16;
                 const int32_t *qrow = P.items;
                 if (q_host) {
@@ -511,17 +511,25 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
                 }
                 const unsigned n_rt = (unsigned)((N + MM16_TILE - 1) / MM16_TILE), n_ct = (unsigned)((nb + MM16_TILE - 1) / MM16_TILE);
                 HIP_TRY(hipFuncSetAttribute((const void *)query_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MM16_LDS));
+                ScopedTimer tf(h, MORNA_T_QUERY_FILTER, 2 * (int64_t)nb * N * h->dpad);   // "bytes" = executed flops
                 hipLaunchKernelGGL(query_scores_kernel, dim3(8u * ((n_rt + 7) / 8) * n_ct), dim3(MM16_THREADS), MM16_LDS, h->stream,
                                    P.X16, N, h->dpad, q16, qrow, (int32_t)nb, scores);
                 P.scores = scores;
             }
+            // beside the contraction (matrix cores, LDS) the traversal is a latency chain on one wave per query: it
+            // runs on the side stream and the refine step waits for both
+            hipStream_t ts = dense ? h->stream2 : h->stream;   // (forked above, before the contraction was enqueued)
             if (bm_lds) {
                 if (lds > 48 * 1024)   // query image + sample bitmap can pass the default dynamic-LDS limit
                     HIP_TRY(hipFuncSetAttribute((const void *)query_traverse_kernel<true>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(query_traverse_kernel<true>, dim3((unsigned)nb), dim3(Q_THREADS), lds, h->stream, P);
+                hipLaunchKernelGGL(query_traverse_kernel<true>, dim3((unsigned)nb), dim3(Q_THREADS), lds, ts, P);
             } else {
-                hipLaunchKernelGGL(query_traverse_kernel<false>, dim3((unsigned)nb), dim3(Q_THREADS), lds_q, h->stream, P);
+                hipLaunchKernelGGL(query_traverse_kernel<false>, dim3((unsigned)nb), dim3(Q_THREADS), lds_q, ts, P);
+            }
+            if (dense) {
+                HIP_TRY(hipEventRecord(h->ev_join, h->stream2));
+                HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
             }
 #define REFINE(MODE)                                                                                                         \
     do {                                                                                                                     \
@@ -971,6 +979,7 @@ int exact_search(morna_index *h, const double *q, int64_t nq, int32_t k, int32_t
             ScopedTimer tm(h, MORNA_T_EXACT, 4 * (int64_t)D * N * ((nb + q_per_pass - 1) / q_per_pass));
             hipLaunchKernelGGL(exact_prep_kernel, dim3((unsigned)((nb * WAVE + 255) / 256)), dim3(256), 0, h->stream,
                                Qd.p, nb, D, dpad, Qf.p, qn2.p);
+            ScopedTimer ts(h, MORNA_T_EXACT_SCAN, nb >= 32 ? 2 * (int64_t)nb * N * dpad : 0);   // "bytes" = flops on the matrix cores
             if (nb >= 32) {   // enough queries to fill MFMA tiles: dense contraction on the matrix cores
                 dim3 grid((unsigned)((N + MM_TILE - 1) / MM_TILE), (unsigned)((nb + MM_TILE - 1) / MM_TILE));
                 hipLaunchKernelGGL(exact_scan_mfma_kernel, grid, dim3(256), 0, h->stream, h->X.p, h->norm2.p, N, dpad, Qf.p,
