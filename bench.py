@@ -124,6 +124,7 @@ def exact_all_pairs_shard(args, device):
     prep = prepare_csr(data["keys"], data["row_ptr"], data["samples"], data["cov"], data["sample_count"], 100)
     a = AnnoyIndex(D, device=device)
     a.stage_junctions(prep["key_bytes"], prep["key_off"], prep["row_ptr"], prep["ids"], prep["cov"], prep["idf"])
+    a.stage_item_order(prep["ext_ids"])
     a.build_features(prep["n_items"])
     a.unstage_junctions()
     Qd = a.get_items().astype(np.float64)
@@ -240,6 +241,7 @@ def main():
     index = AnnoyIndex(D, device=local_rank)
     t_stage = time.perf_counter()   # host -> HBM copy of the junction lines: NOT part of the timed region
     index.stage_junctions(prep["key_bytes"], prep["key_off"], prep["row_ptr"], prep["ids"], prep["cov"], prep["idf"])
+    index.stage_item_order(prep["ext_ids"])   # the sample ids, in which the lines' lists ascend (as go_index sees them)
     t_stage = time.perf_counter() - t_stage
     items = query_items(n_items, Q)              # the queries this rank owns (all of them when world == 1)
     sharded = ShardedSearch(index, rank, world, n_items) if (world > 1 or force_sharded) else None

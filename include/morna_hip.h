@@ -71,6 +71,14 @@ int morna_stage_junctions(morna_index *h, const uint8_t *key_bytes, const int64_
                           const int64_t *row_ptr, const int32_t *item_ids, const int32_t *cov,
                           const double *idf);
 int morna_build_features(morna_index *h, int64_t n_items);
+/*
+ * Optional, before build_features: an ORDER of the items in which the sample lists of the lines ascend --
+ * order_key[i] for internal id i, e.g. the external sample id (an intropolis line lists its samples in ascending
+ * order, morna.py:848-853, while internal ids are first-seen, morna.py:377-382).  Performance only: each entry of the
+ * staged lists is then read once instead of once per sample tile; lines that do not ascend in the order, or no
+ * order at all, give the same matrix.  Dropped by morna_unstage_junctions; ignored unless n_items matches build_features'.
+ */
+int morna_stage_item_order(morna_index *h, const int64_t *order_key, int64_t n_items);
 int morna_unstage_junctions(morna_index *h);
 /* device hash of staged or given keys, for tests: hash/col/sign per key */
 int morna_hash_keys(morna_index *h, const uint8_t *key_bytes, const int64_t *key_off, int64_t J,

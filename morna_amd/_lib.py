@@ -35,6 +35,7 @@ SIGNATURES = {
     "morna_add_items_f32": (C.c_int, [_p, _i32, _p, _i64]),
     "morna_stage_junctions": (C.c_int, [_p, _p, _p, _i64, _p, _p, _p, _p]),
     "morna_build_features": (C.c_int, [_p, _i64]),
+    "morna_stage_item_order": (C.c_int, [_p, _p, _i64]),
     "morna_unstage_junctions": (C.c_int, [_p]),
     "morna_hash_keys": (C.c_int, [_p, _p, _p, _i64, _p, _p, _p]),
     "morna_parse_intropolis": (C.c_int, [C.c_char_p, _i64, _i64, C.POINTER(_p)]),

@@ -117,6 +117,12 @@ class AnnoyIndex(object):
         check(lib().morna_stage_junctions(self._h, ptr(key_bytes), ptr(key_off), J, ptr(row_ptr),
                                           ptr(item_ids), ptr(cov), ptr(idf)))
 
+    def stage_item_order(self, order_key):
+        """order_key[i] for internal id i: a key in which the lines' sample lists ascend (the external sample ids of an
+        intropolis file).  A performance hint for build_features; the matrix does not depend on it."""
+        order_key = np.ascontiguousarray(order_key, dtype=np.int64)
+        check(lib().morna_stage_item_order(self._h, ptr(order_key), len(order_key)))
+
     def build_features(self, n_items):
         check(lib().morna_build_features(self._h, int(n_items)))
 

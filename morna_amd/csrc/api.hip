@@ -1,8 +1,10 @@
 // api.hip -- the extern "C" surface declared in include/morna_hip.h.
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "common.hpp"
 #include "devutil.hpp"
@@ -260,6 +262,34 @@ int morna_stage_junctions(morna_index *h, const uint8_t *key_bytes, const int64_
     return MORNA_OK;
 }
 
+int morna_stage_item_order(morna_index *h, const int64_t *order_key, int64_t n_items)
+{
+    CHECK_H(h);
+    MORNA_TRY(settle(h));
+    if (n_items < 0 || n_items >= INT32_MAX || (n_items > 0 && !order_key)) {
+        set_error("stage_item_order: bad arguments");
+        return MORNA_E_INVALID;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    h->order_n = 0;
+    if (n_items == 0) return MORNA_OK;
+    try {
+        std::vector<int32_t> at((size_t)n_items), rank((size_t)n_items);
+        for (int64_t i = 0; i < n_items; i++) at[(size_t)i] = (int32_t)i;
+        std::stable_sort(at.begin(), at.end(), [&](int32_t a, int32_t b) { return order_key[a] < order_key[b]; });
+        for (int64_t r = 0; r < n_items; r++) rank[(size_t)at[(size_t)r]] = (int32_t)r;
+        MORNA_TRY(h->item_rank.alloc((size_t)n_items));
+        MORNA_TRY(h->item_at.alloc((size_t)n_items));
+        HIP_TRY(hipMemcpy(h->item_rank.p, rank.data(), (size_t)n_items * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->item_at.p, at.data(), (size_t)n_items * 4, hipMemcpyHostToDevice));
+    } catch (const std::exception &e) {
+        set_error("stage_item_order: %s", e.what());
+        return MORNA_E_INVALID;
+    }
+    h->order_n = n_items;
+    return MORNA_OK;
+}
+
 int morna_unstage_junctions(morna_index *h)
 {
     CHECK_H(h);
@@ -267,6 +297,9 @@ int morna_unstage_junctions(morna_index *h)
     h->s_keys.release(); h->s_key_off.release(); h->s_row_ptr.release();
     h->s_ids.release(); h->s_cov.release(); h->s_idf.release();
     for (int i = 0; i < 8; i++) h->scratch[i].release();   // feature-build scratch (fp64 column image ...)
+    h->scratch[24].release();                               // tile extents of the lines
+    h->item_rank.release(); h->item_at.release();
+    h->order_n = 0;
     h->staged = false;
     h->J = h->nnz = h->key_bytes_n = 0;
     return MORNA_OK;

@@ -143,6 +143,10 @@ struct morna_index {
     morna::DevBuf<int32_t> s_ids, s_cov;
     morna::DevBuf<double> s_idf;
     bool staged = false;
+    // optional order of the items in which the lines' sample lists ascend (morna_stage_item_order): rank of every item
+    // and the item at every rank
+    morna::DevBuf<int32_t> item_rank, item_at;
+    int64_t order_n = 0;
 
     // forest
     int32_t n_trees = 0;
@@ -161,7 +165,7 @@ struct morna_index {
     morna::DevBuf<uint8_t> ws;
     // build scratch kept between calls (feature and forest builds reuse it instead of
     // hipMalloc / hipFree on every call); slots are named in features.hip / forest.hip
-    morna::DevBuf<uint8_t> scratch[24];
+    morna::DevBuf<uint8_t> scratch[26];
     // [0] rows read by query kernels (hyperplane dots + candidates + 1 per query)
     morna::DevBuf<unsigned long long> d_stat;
 

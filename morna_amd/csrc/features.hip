@@ -20,6 +20,8 @@
 //   transpose_convert    fp32 [D][N] (each cell rounded once from its fp64 sum) -> fp32 [N][dpad] through an LDS tile
 //   row_norms_kernel     canonical dot(x, x) per row
 #include <algorithm>
+#include <climits>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.hpp"
@@ -138,9 +140,11 @@ __global__ __launch_bounds__(256) void col_place_kernel(const int32_t *__restric
 // though the file's sample list is.)  Uses an LDS bitmap over the samples.
 #define FLAG_MAX_WORDS 32768   // 128 KiB of LDS: up to 2^20 samples
 #define LF_THREADS 1024   // a line holds ~1.4 k samples: one or two per thread
+// upgrade != 0: only the lines whose flag is already non-zero are examined, and their flag becomes 1 + (a sample
+// repeats) -- the lines line_prep_kernel found not ascending (accumulate_wave_kernel's flags 0 / 1 / 2).
 __global__ __launch_bounds__(LF_THREADS) void line_flags_kernel(const int64_t *__restrict__ row_ptr,
                                                          const int32_t *__restrict__ ids, int64_t J,
-                                                         int32_t n_words, uint8_t *__restrict__ flag_out)
+                                                         int32_t n_words, uint8_t *__restrict__ flag_out, int32_t upgrade)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *bm = (uint32_t *)smem;
@@ -149,6 +153,7 @@ __global__ __launch_bounds__(LF_THREADS) void line_flags_kernel(const int64_t *_
     for (int i = tid; i < n_words; i += LF_THREADS) bm[i] = 0u;
     __syncthreads();
     for (int64_t j = blockIdx.x; j < J; j += gridDim.x) {
+        if (upgrade && flag_out[j] == 0) continue;   // uniform over the workgroup; the flag is only written below
         const int64_t b = row_ptr[j], e = row_ptr[j + 1];
         if (tid == 0) s_dup = 0;
         __syncthreads();
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(LF_THREADS) void line_flags_kernel(const int64_t *_
         }
         if (dup) s_dup = 1;
         __syncthreads();
-        if (tid == 0) flag_out[j] = (uint8_t)s_dup;
+        if (tid == 0) flag_out[j] = (uint8_t)(s_dup + (upgrade ? 1 : 0));
         for (int64_t t = b + tid; t < e; t += LF_THREADS) bm[(uint32_t)ids[t] >> 5] = 0u;   // un-set only what was set
         __syncthreads();
     }
@@ -176,14 +181,17 @@ __global__ __launch_bounds__(LF_THREADS) void line_flags_kernel(const int64_t *_
 #define LFW_HELD 32
 __global__ __launch_bounds__(LFW_WAVES * WAVE) void line_flags_wave_kernel(const int64_t *__restrict__ row_ptr,
                                                                             const int32_t *__restrict__ ids, int64_t J,
-                                                                            int32_t n_words, uint8_t *__restrict__ flag_out)
+                                                                            int32_t n_words, uint8_t *__restrict__ flag_out,
+                                                                            int32_t upgrade)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
     uint32_t *bm = (uint32_t *)smem + (size_t)w * n_words;
     for (int i = lane; i < n_words; i += WAVE) bm[i] = 0u;
     const int64_t n_waves = (int64_t)gridDim.x * LFW_WAVES;
+    const uint8_t up = upgrade ? 1 : 0;
     for (int64_t j = (int64_t)blockIdx.x * LFW_WAVES + w; j < J; j += n_waves) {
+        if (upgrade && flag_out[j] == 0) continue;   // uniform over the wave
         const int64_t b = row_ptr[j], e = row_ptr[j + 1];
         int dup = 0;
         if (e - b <= (int64_t)WAVE * LFW_HELD) {
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(LFW_WAVES * WAVE) void line_flags_wave_kernel(const
 #pragma unroll
             for (int u = 0; u < LFW_HELD; u++)
                 if (id[u] != 0xffffffffu) bm[id[u] >> 5] = 0u;
-            if (lane == 0) flag_out[j] = (uint8_t)any_held;
+            if (lane == 0) flag_out[j] = (uint8_t)(any_held + up);
             continue;
         }
         // LFW_UNROLL loads in flight per lane: the line's ids come from HBM, one dependent round trip per load otherwise
@@ -226,8 +234,153 @@ __global__ __launch_bounds__(LFW_WAVES * WAVE) void line_flags_wave_kernel(const
             for (int u = 0; u < LFW_UNROLL; u++)
                 if (id[u] != 0xffffffffu) bm[id[u] >> 5] = 0u;
         }
-        if (lane == 0) flag_out[j] = (uint8_t)any;
+        if (lane == 0) flag_out[j] = (uint8_t)(any + up);
     }
+}
+
+__global__ void flags_to_serial_kernel(uint8_t *__restrict__ flag, int64_t J)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < J && flag[j]) flag[j] = 2;
+}
+
+// ------------------------------------------- lines in item ORDER: tile extents
+//
+// The caller may hand over an ORDER of the items (morna_stage_item_order: any key in which the sample lists of the
+// lines ascend -- for an intropolis file, the external sample id: its lines list their samples in ascending order,
+// while the internal ids are handed out first-seen, morna.py:377-382).  Under that order p = rank[item] a line is a
+// strictly ascending sequence, hence (a) no sample repeats in it and (b) the entries that fall into a tile of
+// consecutive p are a contiguous piece of the line.  line_prep_kernel checks the line and records where each tile's
+// piece begins; accumulate_wave_kernel then reads each entry of the nnz stream ONCE (the tile-by-tile form above reads
+// every line once per tile).  A line that does not ascend is flagged and handled the old way, so the result never
+// depends on the hint.
+#define LP_HELD 32   // entries per lane held in registers: lines of up to 2048 entries in one piece
+template <int TILE_SHIFT>
+__global__ __launch_bounds__(256) void line_prep_kernel(const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ ids,
+                                                        const int32_t *__restrict__ rank, int64_t J, int32_t n_tiles,
+                                                        int32_t *__restrict__ tile_off /* [J][n_tiles + 1] */,
+                                                        uint8_t *__restrict__ flag)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) / WAVE, n_waves = (int64_t)gridDim.x * (256 / WAVE);
+    for (int64_t j = wave; j < J; j += n_waves) {
+        const int64_t b = row_ptr[j];
+        const int32_t len = (int32_t)(row_ptr[j + 1] - b);
+        int32_t *off = tile_off + j * (n_tiles + 1);
+        bool asc = true;
+        int32_t prev_last = -1;   // p of the entry before this piece
+        for (int32_t c0 = 0; c0 < len; c0 += WAVE * LP_HELD) {
+            int32_t p[LP_HELD];
+#pragma unroll
+            for (int u = 0; u < LP_HELD; u++) {
+                const int32_t e = c0 + u * WAVE + lane;
+                p[u] = e < len ? rank[ids[b + e]] : INT32_MAX;   // entries past the end: "ascending" and in no tile
+            }
+#pragma unroll
+            for (int u = 0; u < LP_HELD; u++) {
+                const int32_t e = c0 + u * WAVE + lane;
+                int32_t prv = __shfl_up(p[u], 1, WAVE);
+                const int32_t carry = u == 0 ? prev_last : __builtin_amdgcn_readlane(p[u > 0 ? u - 1 : 0], WAVE - 1);
+                if (lane == 0) prv = carry;
+                if (e < len) {
+                    asc = asc && p[u] > prv;
+                    const int32_t tc = p[u] >> TILE_SHIFT, tp = prv < 0 ? -1 : prv >> TILE_SHIFT;
+                    for (int32_t t = tp + 1; t <= tc && t <= n_tiles; t++) off[t] = e;   // tiles that begin at this entry
+                }
+            }
+            const int32_t last_e = (len - c0 < WAVE * LP_HELD ? len - c0 : WAVE * LP_HELD) - 1;   // last entry of the piece
+            int32_t v = -1;
+#pragma unroll
+            for (int u = 0; u < LP_HELD; u++)
+                if (u == last_e / WAVE) v = p[u];
+            prev_last = __shfl(v, last_e % WAVE, WAVE);
+        }
+        const bool all_asc = __all(asc);
+        const int32_t tl = prev_last < 0 ? -1 : prev_last >> TILE_SHIFT;
+        for (int32_t t = tl + 1 + lane; t <= n_tiles; t += WAVE) off[t] = len;   // tiles behind the last entry (and the end)
+        if (lane == 0) flag[j] = all_asc ? 0 : 1;
+    }
+}
+
+// One WAVE per (column, tile of TILE consecutive positions of the item order): the tile's fp64 accumulators live in the
+// wave's own slice of LDS, the column's lines are walked in file order, and of each line only the piece that falls
+// into the tile is read.  LDS operations of one wave complete in order, so consecutive lines need no barrier; a line
+// touches a cell at most once (ascending, or checked by line_flags), so the lanes of one line never meet in a cell.
+//   flag 0  the line ascends in the item order: its piece [tile_off[t], tile_off[t + 1])
+//   flag 1  it does not, but no sample repeats: the whole line is scanned for entries of this tile
+//   flag 2  a sample repeats: lane 0 replays the line in its own order
+#define AW_G 4   // lines in flight
+template <int TILE>
+__global__ __launch_bounds__(256) void accumulate_wave_kernel(
+    int32_t n_tiles, int32_t n_cols, const int32_t *__restrict__ col_off, const int32_t *__restrict__ col_lines,
+    const double *__restrict__ sidf, const uint8_t *__restrict__ flags, const int64_t *__restrict__ row_ptr,
+    const int32_t *__restrict__ tile_off, const int32_t *__restrict__ ids, const int32_t *__restrict__ cov,
+    const int32_t *__restrict__ rank, int64_t n_items, float *__restrict__ colacc /* [D][n_items], by position in the order */)
+{
+    __shared__ double acc_all[256 / WAVE][TILE];
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    double *acc = acc_all[w];
+    const int64_t g = (int64_t)blockIdx.x * (256 / WAVE) + w;   // consecutive tiles of a column sit in one workgroup
+    const int c = (int)(g / n_tiles), t = (int)(g % n_tiles);
+    if (c >= n_cols) return;   // whole wave; no workgroup barrier anywhere in this kernel
+    const int32_t p_lo = t * TILE;
+    const uint32_t span = (uint32_t)((int64_t)p_lo + TILE < n_items ? TILE : n_items - p_lo);
+    for (int i = lane; i < TILE; i += WAVE) acc[i] = 0.0;
+    const int nl = col_off[c + 1] - col_off[c];
+    const int32_t *lines = col_lines + col_off[c];
+    const int tstride = n_tiles + 1;
+
+    for (int i0 = 0; i0 < nl; i0 += AW_G) {
+        int64_t b[AW_G];
+        int32_t lo[AW_G], hi[AW_G], len[AW_G], fl[AW_G], id[AW_G], cv[AW_G], pp[AW_G];
+        double wgt[AW_G];
+#pragma unroll
+        for (int q = 0; q < AW_G; q++) {
+            const bool live = i0 + q < nl;
+            const int32_t j = lines[live ? i0 + q : i0];
+            b[q] = row_ptr[j];
+            len[q] = live ? (int32_t)(row_ptr[j + 1] - b[q]) : 0;
+            fl[q] = live ? (int32_t)flags[j] : 3;   // 3: nothing to do
+            lo[q] = tile_off[(int64_t)j * tstride + t];
+            hi[q] = tile_off[(int64_t)j * tstride + t + 1];
+            wgt[q] = sidf[j];
+        }
+#pragma unroll
+        for (int q = 0; q < AW_G; q++) {   // the first 64 entries of each ascending line's piece, all in flight together
+            const int32_t e = lo[q] + lane;
+            const bool on = fl[q] == 0 && e < hi[q];
+            id[q] = on ? ids[b[q] + e] : -1;
+            cv[q] = on ? cov[b[q] + e] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < AW_G; q++) pp[q] = id[q] >= 0 ? rank[id[q]] : -1;
+#pragma unroll
+        for (int q = 0; q < AW_G; q++) {
+            const double wq = wgt[q];
+            if (fl[q] == 0) {
+                // tf_idf = cov * idf (one rounding), then += (one rounding): morna.py:384-388
+                if (pp[q] >= 0) acc[pp[q] - p_lo] = __dadd_rn(acc[pp[q] - p_lo], __dmul_rn((double)cv[q], wq));
+                for (int32_t e = lo[q] + WAVE + lane; e < hi[q]; e += WAVE) {   // a piece longer than one wave
+                    const int32_t pe = rank[ids[b[q] + e]];
+                    acc[pe - p_lo] = __dadd_rn(acc[pe - p_lo], __dmul_rn((double)cov[b[q] + e], wq));
+                }
+            } else if (fl[q] == 1) {
+                for (int32_t e = lane; e < len[q]; e += WAVE) {
+                    const uint32_t off = (uint32_t)(rank[ids[b[q] + e]] - p_lo);
+                    if (off < span) acc[off] = __dadd_rn(acc[off], __dmul_rn((double)cov[b[q] + e], wq));
+                }
+            } else if (fl[q] == 2) {
+                if (lane == 0)
+                    for (int32_t e = 0; e < len[q]; e++) {
+                        const uint32_t off = (uint32_t)(rank[ids[b[q] + e]] - p_lo);
+                        if (off < span) acc[off] = __dadd_rn(acc[off], __dmul_rn((double)cov[b[q] + e], wq));
+                    }
+            }
+        }
+    }
+    // the cell's fp64 sum is complete: the one rounding to fp32 (add_item's cast, morna.py:405-424) happens here
+    float *out = colacc + (int64_t)c * n_items + p_lo;
+    for (int i = lane; i < (int)span; i += WAVE) out[i] = __double2float_rn(acc[i]);
 }
 
 // ------------------------------------------------------------ accumulate pass
@@ -323,9 +476,10 @@ __global__ __launch_bounds__(ACC_THREADS) void accumulate_kernel(
 // --------------------------------------------------- fp32 [D][N] -> fp32 [N][dpad]
 
 #define TT 64
+// item_of: the item whose value stands at position n of a column image (null: the identity)
 __global__ __launch_bounds__(256) void transpose_convert_kernel(const float *__restrict__ colacc,
                                                                 int64_t n_items, int32_t dim, int32_t dpad,
-                                                                float *__restrict__ X)
+                                                                const int32_t *__restrict__ item_of, float *__restrict__ X)
 {
     __shared__ float tile[TT][TT + 1];
     const int64_t n0 = (int64_t)blockIdx.x * TT;
@@ -342,7 +496,7 @@ __global__ __launch_bounds__(256) void transpose_convert_kernel(const float *__r
     for (int r = ty; r < TT; r += 4) {
         int64_t n = n0 + r;
         int32_t c = c0 + tx;
-        if (n < n_items && c < dpad) X[n * dpad + c] = tile[tx][r];
+        if (n < n_items && c < dpad) X[(int64_t)(item_of ? item_of[n] : n) * dpad + c] = tile[tx][r];
     }
 }
 
@@ -485,6 +639,13 @@ int build_features(morna_index *h, int64_t n_items)
     ScratchRef<float> colacc(h->scratch[5]);
     ScratchRef<uint8_t> flags(h->scratch[6]);
     ScratchRef<int32_t> bucket_aux(h->scratch[7]);   // [J] rank of a line in its chunk, then [n_chunks][D] chunk counts / bases
+    // with an item order whose length matches: the wave-per-tile form (each entry of the nnz stream read once)
+    static const bool wave_on = !(getenv("MORNA_FEATURES_WAVE") && atoi(getenv("MORNA_FEATURES_WAVE")) == 0);
+    const bool by_order = wave_on && h->order_n == n_items && J > 0;
+    constexpr int AW_TILE_SHIFT = 11, AW_TILE = 1 << AW_TILE_SHIFT;
+    const int32_t aw_tiles = (int32_t)((n_items + AW_TILE - 1) / AW_TILE);
+    ScratchRef<int32_t> tile_off(h->scratch[24]);        // [J][aw_tiles + 1] where each tile's piece of a line begins
+    if (by_order) MORNA_TRY(tile_off.alloc((size_t)J * (size_t)(aw_tiles + 1)));
     // algorithmic bytes of this pass: 8*nnz + keys + 8*J + 4*N*D
     const int64_t alg_bytes = 8 * h->nnz + h->key_bytes_n + 8 * J + 4 * n_items * (int64_t)D;
     MORNA_TRY(col.alloc((size_t)J));
@@ -510,20 +671,32 @@ int build_features(morna_index *h, int64_t n_items)
             HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
             HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
             const int64_t n_words = (n_items + 31) / 32;
+            const int32_t upgrade = by_order ? 1 : 0;
+            if (by_order) {
+                // ascending check + tile extents of every line; the flag kernels below then look at the lines that do
+                // not ascend only (none, for a file whose lines are sorted and an order that says so)
+                const int lp_blocks = (int)std::max<int64_t>(1, std::min<int64_t>((J + 3) / 4, (int64_t)h->n_cus * 8));
+                hipLaunchKernelGGL(line_prep_kernel<AW_TILE_SHIFT>, dim3(lp_blocks), dim3(256), 0, h->stream2, h->s_row_ptr.p,
+                                   h->s_ids.p, h->item_rank.p, J, aw_tiles, tile_off.p, flags.p);
+            }
             if (n_words <= LFW_MAX_WORDS) {
                 const size_t lds = (size_t)LFW_WAVES * (size_t)n_words * 4;
                 HIP_TRY(hipFuncSetAttribute((const void *)line_flags_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 const int64_t per_wg = (J + LFW_WAVES - 1) / LFW_WAVES;
                 const int fl_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(per_wg, (int64_t)h->n_cus * 2));
                 hipLaunchKernelGGL(line_flags_wave_kernel, dim3(fl_blocks), dim3(LFW_WAVES * WAVE), lds, h->stream2,
-                                   h->s_row_ptr.p, h->s_ids.p, J, (int32_t)n_words, flags.p);
+                                   h->s_row_ptr.p, h->s_ids.p, J, (int32_t)n_words, flags.p, upgrade);
             } else if (n_words <= FLAG_MAX_WORDS) {
                 const int fl_blocks = (int)std::min<int64_t>(J, 256 * 4);
                 hipLaunchKernelGGL(line_flags_kernel, dim3(fl_blocks), dim3(LF_THREADS), (size_t)n_words * 4, h->stream2,
-                                   h->s_row_ptr.p, h->s_ids.p, J, (int32_t)n_words, flags.p);
+                                   h->s_row_ptr.p, h->s_ids.p, J, (int32_t)n_words, flags.p, upgrade);
             } else {
-                // the sample bitmap does not fit LDS: take the order-preserving serial path for every line
-                HIP_TRY(hipMemsetAsync(flags.p, 1, (size_t)J, h->stream2));
+                // the sample bitmap does not fit LDS: the order-preserving serial path for every line (by_order: for
+                // every line that does not ascend -- flag 1 -> 2; ascending lines need no such test)
+                if (by_order)
+                    hipLaunchKernelGGL(flags_to_serial_kernel, dim3((unsigned)((J + 255) / 256)), dim3(256), 0, h->stream2, flags.p, J);
+                else
+                    HIP_TRY(hipMemsetAsync(flags.p, 1, (size_t)J, h->stream2));
             }
             HIP_TRY(hipEventRecord(h->ev_join, h->stream2));
         }
@@ -540,15 +713,22 @@ int build_features(morna_index *h, int64_t n_items)
                                line_rank, chunk_cnt, col_off.p, col_lines.p);
         }
         if (J > 0) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
-        const unsigned tiles = (unsigned)((n_items + ACC_TILE - 1) / ACC_TILE);
-        // workgroup b runs on XCD b % 8: the sample tiles of one column are dealt to ONE XCD, back to back, so the
-        // column's lines come from HBM once and from that XCD's L2 for the other tiles
-        hipLaunchKernelGGL(accumulate_kernel, dim3(8u * tiles * (unsigned)((D + 7) / 8)), dim3(ACC_THREADS), 0, h->stream,
-                           (int32_t)tiles, (int32_t)D, col_off.p, col_lines.p, sidf.p, flags.p, h->s_row_ptr.p, h->s_ids.p,
-                           h->s_cov.p, n_items, colacc.p);
+        if (by_order) {
+            const int64_t waves = (int64_t)D * aw_tiles;
+            hipLaunchKernelGGL(accumulate_wave_kernel<AW_TILE>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, h->stream, aw_tiles,
+                               (int32_t)D, col_off.p, col_lines.p, sidf.p, flags.p, h->s_row_ptr.p, tile_off.p, h->s_ids.p,
+                               h->s_cov.p, h->item_rank.p, n_items, colacc.p);
+        } else {
+            const unsigned tiles = (unsigned)((n_items + ACC_TILE - 1) / ACC_TILE);
+            // workgroup b runs on XCD b % 8: the sample tiles of one column are dealt to ONE XCD, back to back, so the
+            // column's lines come from HBM once and from that XCD's L2 for the other tiles
+            hipLaunchKernelGGL(accumulate_kernel, dim3(8u * tiles * (unsigned)((D + 7) / 8)), dim3(ACC_THREADS), 0, h->stream,
+                               (int32_t)tiles, (int32_t)D, col_off.p, col_lines.p, sidf.p, flags.p, h->s_row_ptr.p, h->s_ids.p,
+                               h->s_cov.p, n_items, colacc.p);
+        }
         dim3 tg((unsigned)((n_items + TT - 1) / TT), (unsigned)((h->dpad + TT - 1) / TT));
         hipLaunchKernelGGL(transpose_convert_kernel, tg, dim3(256), 0, h->stream, colacc.p, n_items, D, h->dpad,
-                           h->X.p);
+                           by_order ? (const int32_t *)h->item_at.p : (const int32_t *)nullptr, h->X.p);
         HIP_TRY(hipGetLastError());
         h->n_items = n_items;
         h->host_n = 0;

@@ -400,8 +400,10 @@ int morna_stage_lines(morna_index *h, const morna_lines *L)
         set_error("stage_lines: null argument");
         return MORNA_E_INVALID;
     }
-    return morna_stage_junctions(h, L->key_bytes.data(), L->key_off.data(), (int64_t)L->idf.size(), L->row_ptr.data(),
-                                 L->item_ids.data(), L->cov.data(), L->idf.data());
+    MORNA_TRY(morna_stage_junctions(h, L->key_bytes.data(), L->key_off.data(), (int64_t)L->idf.size(), L->row_ptr.data(),
+                                    L->item_ids.data(), L->cov.data(), L->idf.data()));
+    // the file's lines list their samples in ascending order of the external id: hand that order over with them
+    return morna_stage_item_order(h, L->ext_ids.data(), (int64_t)L->ext_ids.size());
 }
 
 }  // extern "C"

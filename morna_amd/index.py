@@ -125,6 +125,13 @@ class MornaIndex(AnnoyIndex):
                              + "caused when no junctions pass the sample "
                              + "threshold.")
         self.stage_junctions(*self._lines.arrays())
+        # intropolis lines list their samples by ascending sample id: that order lets the GPU read each (sample,
+        # coverage) pair once (a hint: the matrix is the same without it)
+        by_internal = sorted(self.internal_id_map, key=self.internal_id_map.get)
+        try:
+            self.stage_item_order(np.asarray(by_internal, dtype=np.int64))
+        except (TypeError, ValueError, OverflowError):
+            pass                                        # sample ids that are not integers: no hint
         self.build_features(self.new_internal_id)
         self.unstage_junctions()
         if verbose:

@@ -44,6 +44,7 @@ def c3():
     prep = prepare_csr(data["keys"], data["row_ptr"], data["samples"], data["cov"], data["sample_count"], 100)
     a = AnnoyIndex(D3)
     a.stage_junctions(prep["key_bytes"], prep["key_off"], prep["row_ptr"], prep["ids"], prep["cov"], prep["idf"])
+    a.stage_item_order(prep["ext_ids"])
     a.build_features(prep["n_items"])
     a.build(T3, seed=0)
     X = a.get_items()

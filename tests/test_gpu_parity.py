@@ -40,12 +40,19 @@ def _tokenized(morna_ref, lines):
     return keys, np.array(rp, np.int64), np.array(s, np.int64), np.array(c, np.int64)
 
 
-def _gpu_features(keys, rp, s, c, sample_count, threshold, D):
+def _gpu_features(keys, rp, s, c, sample_count, threshold, D, order=None):
+    """order: None -> no item order staged (tile-by-tile accumulation); "ext" -> the external sample ids (the order the
+    host paths hand over: lines listed by ascending sample id are then read once, the others take the flagged paths);
+    "reversed" -> an order in which NO ascending line ascends (every line goes the flagged way)."""
     from morna_amd.annoy import AnnoyIndex
     from morna_amd.index import prepare_csr
     prep = prepare_csr(keys, rp, s, c, sample_count, threshold)
     a = AnnoyIndex(D)
     a.stage_junctions(prep["key_bytes"], prep["key_off"], prep["row_ptr"], prep["ids"], prep["cov"], prep["idf"])
+    if order == "ext":
+        a.stage_item_order(prep["ext_ids"])
+    elif order == "reversed":
+        a.stage_item_order(-np.asarray(prep["ext_ids"], np.int64))
     a.build_features(prep["n_items"])
     return a, prep
 
@@ -79,6 +86,8 @@ def test_features_embedded_fixtures(embedded, embedded_mats, morna_ref, name, D)
     assert prep["n_items"] == spec["n_items"] == a.get_n_items()
     X = a.get_items()
     assert X.tobytes() == embedded_mats["%s_D%d_f32" % (name, D)].tobytes()
+    b, _ = _gpu_features(keys, rp, s, c, spec["sample_count"], spec["sample_threshold"], D, "ext")   # the lossy fixture lists
+    assert b.get_items().tobytes() == X.tobytes()                                                    # its samples descending
     assert prep["ext_ids"].tolist() == embedded_mats["%s_D%d_ext_ids" % (name, D)].tolist()
 
 
@@ -87,8 +96,9 @@ def test_features_tiny_intropolis(morna_ref):
     with open(os.path.join(GOLDEN, "tiny_intropolis.tsv")) as fh:
         lines = fh.readlines()
     keys, rp, s, c = _tokenized(morna_ref, lines)
-    a, prep = _gpu_features(keys, rp, s, c, 6850, 100, 128)
+    a, prep = _gpu_features(keys, rp, s, c, 6850, 100, 128, "ext")
     assert a.get_items().tobytes() == g["X"].tobytes()
+    assert _gpu_features(keys, rp, s, c, 6850, 100, 128)[0].get_items().tobytes() == g["X"].tobytes()
     assert prep["ext_ids"].tolist() == g["ext_ids"].tolist()
 
 
@@ -118,17 +128,31 @@ def _synthetic_lines(rng, n_samples, J, lo, hi, dup_keys=True, weird=True):
 @pytest.mark.parametrize("D,n_samples,J", [(64, 700, 1500), (3000, 2000, 3000), (257, 300, 50),
                                            (40, 70000, 4500)])   # > 65536 samples: the duplicate flags of the lines
                                                                  # come from the workgroup-per-line kernel
-def test_features_synthetic_vs_oracle(capi, D, n_samples, J):
+@pytest.mark.parametrize("order", [None, "ext", "reversed"])
+def test_features_synthetic_vs_oracle(capi, D, n_samples, J, order):
     rng = np.random.default_rng(8675309 + D)
     keys, rp, s, c = _synthetic_lines(rng, n_samples, J, 5, 120)
     buf, off = capi.pack_keys(keys)
     ref = capi.index_features(buf, off, rp, s, c, n_samples, 20, D)
-    a, prep = _gpu_features(keys, rp, s, c, n_samples, 20, D)
+    a, prep = _gpu_features(keys, rp, s, c, n_samples, 20, D, order)
     assert prep["n_items"] == ref["n_items"]
     assert n_samples < 65536 or prep["n_items"] > 65536
     assert prep["ext_ids"].tolist() == ref["ext_ids"].tolist()
     assert prep["skipped"] == ref["skipped"]
     assert a.get_items().tobytes() == ref["X"].tobytes()
+
+
+def test_features_long_lines_with_item_order(capi):
+    """Lines of up to 9000 samples (several 2048-entry pieces per wave in line_prep_kernel, pieces of a tile longer
+    than one wave in accumulate_wave_kernel), 5000 samples = 3 tiles of the item order, the last one ragged."""
+    rng = np.random.default_rng(31)
+    n_samples, J, D = 9500, 260, 96
+    keys, rp, s, c = _synthetic_lines(rng, n_samples, J, 40, 9000, dup_keys=True, weird=True)
+    buf, off = capi.pack_keys(keys)
+    ref = capi.index_features(buf, off, rp, s, c, n_samples, 20, D)
+    for order in ("ext", None):
+        a, prep = _gpu_features(keys, rp, s, c, n_samples, 20, D, order)
+        assert a.get_items().tobytes() == ref["X"].tobytes(), order
 
 
 def test_row_norms_canonical(capi):
