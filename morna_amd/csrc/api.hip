@@ -298,6 +298,7 @@ int morna_unstage_junctions(morna_index *h)
     h->s_ids.release(); h->s_cov.release(); h->s_idf.release();
     for (int i = 0; i < 8; i++) h->scratch[i].release();   // feature-build scratch (fp64 column image ...)
     h->scratch[24].release();                               // tile extents of the lines
+    h->scratch[25].release();                               // positions of the entries' items
     h->item_rank.release(); h->item_at.release();
     h->order_n = 0;
     h->staged = false;

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void col_place_kernel(const int32_t *__restric
 #define FLAG_MAX_WORDS 32768   // 128 KiB of LDS: up to 2^20 samples
 #define LF_THREADS 1024   // a line holds ~1.4 k samples: one or two per thread
 // upgrade != 0: only the lines whose flag is already non-zero are examined, and their flag becomes 1 + (a sample
-// repeats) -- the lines line_prep_kernel found not ascending (accumulate_wave_kernel's flags 0 / 1 / 2).
+// repeats) -- the lines line_prep_kernel found not ascending (accumulate_piece_kernel's flags 0 / 1 / 2).
 __global__ __launch_bounds__(LF_THREADS) void line_flags_kernel(const int64_t *__restrict__ row_ptr,
                                                          const int32_t *__restrict__ ids, int64_t J,
                                                          int32_t n_words, uint8_t *__restrict__ flag_out, int32_t upgrade)
@@ -251,14 +251,61 @@ __global__ void flags_to_serial_kernel(uint8_t *__restrict__ flag, int64_t J)
 // while the internal ids are handed out first-seen, morna.py:377-382).  Under that order p = rank[item] a line is a
 // strictly ascending sequence, hence (a) no sample repeats in it and (b) the entries that fall into a tile of
 // consecutive p are a contiguous piece of the line.  line_prep_kernel checks the line and records where each tile's
-// piece begins; accumulate_wave_kernel then reads each entry of the nnz stream ONCE (the tile-by-tile form above reads
+// piece begins; accumulate_piece_kernel then reads each entry of the nnz stream ONCE (the tile-by-tile form above reads
 // every line once per tile).  A line that does not ascend is flagged and handled the old way, so the result never
 // depends on the hint.
 #define LP_HELD 32   // entries per lane held in registers: lines of up to 2048 entries in one piece
+// One piece of a line (up to NU * 64 entries from entry c0): positions of its items, ascending test, tile starts.
+// Branch-free over the NU register sets -- every load of a phase is in flight before the first result is used; entries
+// past the end of the line re-read its first entry and are masked afterwards.
+template <int TILE_SHIFT, int NU>
+__device__ inline void line_prep_piece(const int32_t *__restrict__ ids, const int32_t *__restrict__ rank, int64_t b, int32_t len,
+                                       int32_t c0, int32_t n_tiles, int32_t *__restrict__ off, int32_t *__restrict__ pid,
+                                       int lane, bool &asc, int32_t &prev_last)
+{
+    int32_t p[NU];
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+        const int32_t e = c0 + u * WAVE + lane;
+        p[u] = ids[b + (e < len ? e : c0)];
+    }
+#pragma unroll
+    for (int u = 0; u < NU; u++) p[u] = rank[p[u]];
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+        const int32_t e = c0 + u * WAVE + lane;
+        if (e < len) pid[b + e] = p[u];
+        else p[u] = INT32_MAX;   // past the end: in no tile
+    }
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+        const int32_t e = c0 + u * WAVE + lane;
+        int32_t prv = __shfl_up(p[u], 1, WAVE);
+        const int32_t carry = u == 0 ? prev_last : __builtin_amdgcn_readlane(p[u > 0 ? u - 1 : 0], WAVE - 1);
+        if (lane == 0) prv = carry;
+        const bool valid = e < len;
+        asc = asc && (!valid || p[u] > prv);
+        const int32_t tc = p[u] >> TILE_SHIFT, tp = prv < 0 ? -1 : prv >> TILE_SHIFT;
+        const bool edge = valid && tc != tp;   // a tile (or several) begins at this entry: ~n_tiles times per line
+        if (__any(edge)) {
+            if (edge)
+                for (int32_t t = tp + 1; t <= tc && t <= n_tiles; t++) off[t] = e;
+        }
+    }
+    const int32_t in_piece = len - c0 < WAVE * NU ? len - c0 : WAVE * NU;
+    const int32_t last_e = in_piece - 1;
+    int32_t v = -1;
+#pragma unroll
+    for (int u = 0; u < NU; u++)
+        if (u == last_e / WAVE) v = p[u];
+    prev_last = __shfl(v, last_e % WAVE, WAVE);
+}
+
 template <int TILE_SHIFT>
 __global__ __launch_bounds__(256) void line_prep_kernel(const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ ids,
                                                         const int32_t *__restrict__ rank, int64_t J, int32_t n_tiles,
                                                         int32_t *__restrict__ tile_off /* [J][n_tiles + 1] */,
+                                                        int32_t *__restrict__ pid /* [nnz] position of each entry's item */,
                                                         uint8_t *__restrict__ flag)
 {
     const int lane = threadIdx.x & (WAVE - 1);
@@ -268,32 +315,22 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const int64_t *__restric
         const int32_t len = (int32_t)(row_ptr[j + 1] - b);
         int32_t *off = tile_off + j * (n_tiles + 1);
         bool asc = true;
-        int32_t prev_last = -1;   // p of the entry before this piece
-        for (int32_t c0 = 0; c0 < len; c0 += WAVE * LP_HELD) {
-            int32_t p[LP_HELD];
-#pragma unroll
-            for (int u = 0; u < LP_HELD; u++) {
-                const int32_t e = c0 + u * WAVE + lane;
-                p[u] = e < len ? rank[ids[b + e]] : INT32_MAX;   // entries past the end: "ascending" and in no tile
+        int32_t prev_last = -1;   // position of the entry before this piece
+        for (int32_t c0 = 0; c0 < len;) {
+            const int32_t left = len - c0;   // uniform: the piece takes the smallest register set that holds what is left
+            if (left > WAVE * 24) {
+                line_prep_piece<TILE_SHIFT, 32>(ids, rank, b, len, c0, n_tiles, off, pid, lane, asc, prev_last);
+                c0 += WAVE * 32;
+            } else if (left > WAVE * 16) {
+                line_prep_piece<TILE_SHIFT, 24>(ids, rank, b, len, c0, n_tiles, off, pid, lane, asc, prev_last);
+                c0 += WAVE * 24;
+            } else if (left > WAVE * 8) {
+                line_prep_piece<TILE_SHIFT, 16>(ids, rank, b, len, c0, n_tiles, off, pid, lane, asc, prev_last);
+                c0 += WAVE * 16;
+            } else {
+                line_prep_piece<TILE_SHIFT, 8>(ids, rank, b, len, c0, n_tiles, off, pid, lane, asc, prev_last);
+                c0 += WAVE * 8;
             }
-#pragma unroll
-            for (int u = 0; u < LP_HELD; u++) {
-                const int32_t e = c0 + u * WAVE + lane;
-                int32_t prv = __shfl_up(p[u], 1, WAVE);
-                const int32_t carry = u == 0 ? prev_last : __builtin_amdgcn_readlane(p[u > 0 ? u - 1 : 0], WAVE - 1);
-                if (lane == 0) prv = carry;
-                if (e < len) {
-                    asc = asc && p[u] > prv;
-                    const int32_t tc = p[u] >> TILE_SHIFT, tp = prv < 0 ? -1 : prv >> TILE_SHIFT;
-                    for (int32_t t = tp + 1; t <= tc && t <= n_tiles; t++) off[t] = e;   // tiles that begin at this entry
-                }
-            }
-            const int32_t last_e = (len - c0 < WAVE * LP_HELD ? len - c0 : WAVE * LP_HELD) - 1;   // last entry of the piece
-            int32_t v = -1;
-#pragma unroll
-            for (int u = 0; u < LP_HELD; u++)
-                if (u == last_e / WAVE) v = p[u];
-            prev_last = __shfl(v, last_e % WAVE, WAVE);
         }
         const bool all_asc = __all(asc);
         const int32_t tl = prev_last < 0 ? -1 : prev_last >> TILE_SHIFT;
@@ -302,85 +339,100 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const int64_t *__restric
     }
 }
 
-// One WAVE per (column, tile of TILE consecutive positions of the item order): the tile's fp64 accumulators live in the
-// wave's own slice of LDS, the column's lines are walked in file order, and of each line only the piece that falls
-// into the tile is read.  LDS operations of one wave complete in order, so consecutive lines need no barrier; a line
-// touches a cell at most once (ascending, or checked by line_flags), so the lanes of one line never meet in a cell.
+// One workgroup of four waves per (column, tile of TILE consecutive positions of the item order): the tile's fp64
+// accumulators live in LDS, the column's lines are walked in file order, and of each line only the piece that falls
+// into the tile is read -- a thread has at most one entry of a piece (pieces longer than the workgroup take more rounds),
+// so ALL the pieces of up to AW_LINES lines are fetched into registers at once, and the line loop itself is LDS
+// read-modify-writes with one barrier per line (a cell may be touched by different threads in consecutive lines; a line
+// touches a cell at most once: it ascends, or line_flags checked it).
 //   flag 0  the line ascends in the item order: its piece [tile_off[t], tile_off[t + 1])
 //   flag 1  it does not, but no sample repeats: the whole line is scanned for entries of this tile
-//   flag 2  a sample repeats: lane 0 replays the line in its own order
-#define AW_G 4   // lines in flight
+//   flag 2  a sample repeats: thread 0 replays the line in its own order
+#define AW_THREADS 256
+#define AW_LINES 32    // lines per pass: their extents staged in LDS, their pieces held in registers
 template <int TILE>
-__global__ __launch_bounds__(256) void accumulate_wave_kernel(
+__global__ __launch_bounds__(AW_THREADS) void accumulate_piece_kernel(
     int32_t n_tiles, int32_t n_cols, const int32_t *__restrict__ col_off, const int32_t *__restrict__ col_lines,
     const double *__restrict__ sidf, const uint8_t *__restrict__ flags, const int64_t *__restrict__ row_ptr,
-    const int32_t *__restrict__ tile_off, const int32_t *__restrict__ ids, const int32_t *__restrict__ cov,
-    const int32_t *__restrict__ rank, int64_t n_items, float *__restrict__ colacc /* [D][n_items], by position in the order */)
+    const int32_t *__restrict__ tile_off, const int32_t *__restrict__ pid, const int32_t *__restrict__ cov,
+    int64_t n_items, float *__restrict__ colacc /* [D][n_items], by position in the order */)
 {
-    __shared__ double acc_all[256 / WAVE][TILE];
-    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-    double *acc = acc_all[w];
-    const int64_t g = (int64_t)blockIdx.x * (256 / WAVE) + w;   // consecutive tiles of a column sit in one workgroup
-    const int c = (int)(g / n_tiles), t = (int)(g % n_tiles);
-    if (c >= n_cols) return;   // whole wave; no workgroup barrier anywhere in this kernel
+    __shared__ double acc[TILE];
+    __shared__ int64_t s_b[AW_LINES];
+    __shared__ double s_w[AW_LINES];
+    __shared__ int32_t s_lo[AW_LINES], s_hi[AW_LINES], s_len[AW_LINES], s_fl[AW_LINES];
+    const int tid = threadIdx.x;
+    const int c = (int)(blockIdx.x / n_tiles), t = (int)(blockIdx.x % n_tiles);   // consecutive tiles of a column: neighbours
     const int32_t p_lo = t * TILE;
     const uint32_t span = (uint32_t)((int64_t)p_lo + TILE < n_items ? TILE : n_items - p_lo);
-    for (int i = lane; i < TILE; i += WAVE) acc[i] = 0.0;
+    for (int i = tid; i < TILE; i += AW_THREADS) acc[i] = 0.0;
     const int nl = col_off[c + 1] - col_off[c];
     const int32_t *lines = col_lines + col_off[c];
     const int tstride = n_tiles + 1;
 
-    for (int i0 = 0; i0 < nl; i0 += AW_G) {
-        int64_t b[AW_G];
-        int32_t lo[AW_G], hi[AW_G], len[AW_G], fl[AW_G], id[AW_G], cv[AW_G], pp[AW_G];
-        double wgt[AW_G];
+    auto rmw = [&](int32_t p, int32_t cv, double wq) {
+        // tf_idf = cov * idf (one rounding), then += (one rounding): morna.py:384-388
+        acc[p - p_lo] = __dadd_rn(acc[p - p_lo], __dmul_rn((double)cv, wq));
+    };
+    for (int l0 = 0; l0 < nl; l0 += AW_LINES) {
+        const int nlc = nl - l0 < AW_LINES ? nl - l0 : AW_LINES;
+        __syncthreads();   // the previous pass is done with the staged extents (and the zeroing above is complete)
+        if (tid < nlc) {   // one thread per line: every look-up of the pass in flight at once
+            const int32_t j = lines[l0 + tid];
+            const int64_t b = row_ptr[j];
+            const int32_t f = (int32_t)flags[j];
+            const int32_t lo = tile_off[(int64_t)j * tstride + t], hi = tile_off[(int64_t)j * tstride + t + 1];
+            s_b[tid] = b;
+            s_len[tid] = (int32_t)(row_ptr[j + 1] - b);
+            s_fl[tid] = f;
+            s_lo[tid] = f == 0 ? lo : 0;   // the extents of a line that does not ascend mean nothing
+            s_hi[tid] = f == 0 ? hi : 0;
+            s_w[tid] = sidf[j];
+        }
+        __syncthreads();
+        // every load unconditional (a thread with no entry in a piece re-reads entry 0 of the arrays; the line loop knows
+        // which threads count): a select on the loaded value would make each load wait for itself
+        int32_t P[AW_LINES], C[AW_LINES];
 #pragma unroll
-        for (int q = 0; q < AW_G; q++) {
-            const bool live = i0 + q < nl;
-            const int32_t j = lines[live ? i0 + q : i0];
-            b[q] = row_ptr[j];
-            len[q] = live ? (int32_t)(row_ptr[j + 1] - b[q]) : 0;
-            fl[q] = live ? (int32_t)flags[j] : 3;   // 3: nothing to do
-            lo[q] = tile_off[(int64_t)j * tstride + t];
-            hi[q] = tile_off[(int64_t)j * tstride + t + 1];
-            wgt[q] = sidf[j];
+        for (int i = 0; i < AW_LINES; i++) {
+            const int ii = i < nlc ? i : 0;
+            const int32_t e = s_lo[ii] + tid;
+            const int64_t at = e < s_hi[ii] ? s_b[ii] + e : 0;
+            P[i] = pid[at];
+            C[i] = cov[at];
         }
 #pragma unroll
-        for (int q = 0; q < AW_G; q++) {   // the first 64 entries of each ascending line's piece, all in flight together
-            const int32_t e = lo[q] + lane;
-            const bool on = fl[q] == 0 && e < hi[q];
-            id[q] = on ? ids[b[q] + e] : -1;
-            cv[q] = on ? cov[b[q] + e] : 0;
-        }
-#pragma unroll
-        for (int q = 0; q < AW_G; q++) pp[q] = id[q] >= 0 ? rank[id[q]] : -1;
-#pragma unroll
-        for (int q = 0; q < AW_G; q++) {
-            const double wq = wgt[q];
-            if (fl[q] == 0) {
-                // tf_idf = cov * idf (one rounding), then += (one rounding): morna.py:384-388
-                if (pp[q] >= 0) acc[pp[q] - p_lo] = __dadd_rn(acc[pp[q] - p_lo], __dmul_rn((double)cv[q], wq));
-                for (int32_t e = lo[q] + WAVE + lane; e < hi[q]; e += WAVE) {   // a piece longer than one wave
-                    const int32_t pe = rank[ids[b[q] + e]];
-                    acc[pe - p_lo] = __dadd_rn(acc[pe - p_lo], __dmul_rn((double)cov[b[q] + e], wq));
-                }
-            } else if (fl[q] == 1) {
-                for (int32_t e = lane; e < len[q]; e += WAVE) {
-                    const uint32_t off = (uint32_t)(rank[ids[b[q] + e]] - p_lo);
-                    if (off < span) acc[off] = __dadd_rn(acc[off], __dmul_rn((double)cov[b[q] + e], wq));
-                }
-            } else if (fl[q] == 2) {
-                if (lane == 0)
-                    for (int32_t e = 0; e < len[q]; e++) {
-                        const uint32_t off = (uint32_t)(rank[ids[b[q] + e]] - p_lo);
-                        if (off < span) acc[off] = __dadd_rn(acc[off], __dmul_rn((double)cov[b[q] + e], wq));
+        for (int i = 0; i < AW_LINES; i++) {
+            if (i < nlc) {   // uniform
+                const int fl = __builtin_amdgcn_readfirstlane(s_fl[i]);
+                const double wq = s_w[i];
+                const int64_t b = s_b[i];
+                if (fl == 0) {
+                    const int32_t lo = __builtin_amdgcn_readfirstlane(s_lo[i]), hi = __builtin_amdgcn_readfirstlane(s_hi[i]);
+                    if (lo + tid < hi) rmw(P[i], C[i], wq);
+                    for (int32_t e = lo + AW_THREADS + tid; e < hi; e += AW_THREADS)   // a piece longer than the workgroup
+                        rmw(pid[b + e], cov[b + e], wq);
+                } else {
+                    const int32_t len = __builtin_amdgcn_readfirstlane(s_len[i]);
+                    if (fl == 1) {
+                        for (int32_t e = tid; e < len; e += AW_THREADS) {
+                            const int32_t p = pid[b + e];
+                            if ((uint32_t)(p - p_lo) < span) rmw(p, cov[b + e], wq);
+                        }
+                    } else if (tid == 0) {
+                        for (int32_t e = 0; e < len; e++) {
+                            const int32_t p = pid[b + e];
+                            if ((uint32_t)(p - p_lo) < span) rmw(p, cov[b + e], wq);
+                        }
                     }
+                }
+                __syncthreads();   // the next line of this column may touch the same cells from other threads
             }
         }
     }
     // the cell's fp64 sum is complete: the one rounding to fp32 (add_item's cast, morna.py:405-424) happens here
     float *out = colacc + (int64_t)c * n_items + p_lo;
-    for (int i = lane; i < (int)span; i += WAVE) out[i] = __double2float_rn(acc[i]);
+    for (int i = tid; i < (int)span; i += AW_THREADS) out[i] = __double2float_rn(acc[i]);
 }
 
 // ------------------------------------------------------------ accumulate pass
@@ -482,7 +534,12 @@ __global__ __launch_bounds__(256) void transpose_convert_kernel(const float *__r
                                                                 const int32_t *__restrict__ item_of, float *__restrict__ X)
 {
     __shared__ float tile[TT][TT + 1];
+    __shared__ int32_t s_item[TT];
     const int64_t n0 = (int64_t)blockIdx.x * TT;
+    if (threadIdx.x < TT) {
+        const int64_t n = n0 + threadIdx.x;
+        s_item[threadIdx.x] = n < n_items ? (item_of ? item_of[n] : (int32_t)n) : 0;
+    }
     const int32_t c0 = blockIdx.y * TT;
     const int tx = threadIdx.x & (TT - 1), ty = threadIdx.x / TT;   // 64 x 4
     for (int r = ty; r < TT; r += 4) {
@@ -496,7 +553,7 @@ __global__ __launch_bounds__(256) void transpose_convert_kernel(const float *__r
     for (int r = ty; r < TT; r += 4) {
         int64_t n = n0 + r;
         int32_t c = c0 + tx;
-        if (n < n_items && c < dpad) X[(int64_t)(item_of ? item_of[n] : n) * dpad + c] = tile[tx][r];
+        if (n < n_items && c < dpad) X[(int64_t)s_item[r] * dpad + c] = tile[tx][r];
     }
 }
 
@@ -642,10 +699,12 @@ int build_features(morna_index *h, int64_t n_items)
     // with an item order whose length matches: the wave-per-tile form (each entry of the nnz stream read once)
     static const bool wave_on = !(getenv("MORNA_FEATURES_WAVE") && atoi(getenv("MORNA_FEATURES_WAVE")) == 0);
     const bool by_order = wave_on && h->order_n == n_items && J > 0;
-    constexpr int AW_TILE_SHIFT = 11, AW_TILE = 1 << AW_TILE_SHIFT;
+    constexpr int AW_TILE_SHIFT = 12, AW_TILE = 1 << AW_TILE_SHIFT;   // 4096 positions: 0.61 ms at C3 (2048: 0.76, 8192: 0.83)
     const int32_t aw_tiles = (int32_t)((n_items + AW_TILE - 1) / AW_TILE);
     ScratchRef<int32_t> tile_off(h->scratch[24]);        // [J][aw_tiles + 1] where each tile's piece of a line begins
+    ScratchRef<int32_t> pid(h->scratch[25]);             // [nnz] position in the order of every entry's item
     if (by_order) MORNA_TRY(tile_off.alloc((size_t)J * (size_t)(aw_tiles + 1)));
+    if (by_order) MORNA_TRY(pid.alloc((size_t)h->nnz));
     // algorithmic bytes of this pass: 8*nnz + keys + 8*J + 4*N*D
     const int64_t alg_bytes = 8 * h->nnz + h->key_bytes_n + 8 * J + 4 * n_items * (int64_t)D;
     MORNA_TRY(col.alloc((size_t)J));
@@ -677,7 +736,7 @@ int build_features(morna_index *h, int64_t n_items)
                 // not ascend only (none, for a file whose lines are sorted and an order that says so)
                 const int lp_blocks = (int)std::max<int64_t>(1, std::min<int64_t>((J + 3) / 4, (int64_t)h->n_cus * 8));
                 hipLaunchKernelGGL(line_prep_kernel<AW_TILE_SHIFT>, dim3(lp_blocks), dim3(256), 0, h->stream2, h->s_row_ptr.p,
-                                   h->s_ids.p, h->item_rank.p, J, aw_tiles, tile_off.p, flags.p);
+                                   h->s_ids.p, h->item_rank.p, J, aw_tiles, tile_off.p, pid.p, flags.p);
             }
             if (n_words <= LFW_MAX_WORDS) {
                 const size_t lds = (size_t)LFW_WAVES * (size_t)n_words * 4;
@@ -714,10 +773,9 @@ int build_features(morna_index *h, int64_t n_items)
         }
         if (J > 0) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
         if (by_order) {
-            const int64_t waves = (int64_t)D * aw_tiles;
-            hipLaunchKernelGGL(accumulate_wave_kernel<AW_TILE>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, h->stream, aw_tiles,
-                               (int32_t)D, col_off.p, col_lines.p, sidf.p, flags.p, h->s_row_ptr.p, tile_off.p, h->s_ids.p,
-                               h->s_cov.p, h->item_rank.p, n_items, colacc.p);
+            hipLaunchKernelGGL(accumulate_piece_kernel<AW_TILE>, dim3((unsigned)D * (unsigned)aw_tiles), dim3(AW_THREADS), 0, h->stream, aw_tiles,
+                               (int32_t)D, col_off.p, col_lines.p, sidf.p, flags.p, h->s_row_ptr.p, tile_off.p, pid.p,
+                               h->s_cov.p, n_items, colacc.p);
         } else {
             const unsigned tiles = (unsigned)((n_items + ACC_TILE - 1) / ACC_TILE);
             // workgroup b runs on XCD b % 8: the sample tiles of one column are dealt to ONE XCD, back to back, so the
