@@ -112,6 +112,10 @@ int morna_stage_lines(morna_index *h, const morna_lines *L);
 int morna_lines_save(const morna_lines *L, const char *path, const int64_t *tag);
 int morna_lines_load(const char *path, int64_t *tag_out, morna_lines **out);
 int morna_lines_free(morna_lines *L);
+/* Benchmark / test utility (no counterpart in the reference): J lines written as an intropolis text file, gzipped when
+ * the path ends in ".gz": key words, "+", "GT", "AG", the sample list, the coverage list, tab separated. */
+int morna_write_intropolis(const char *path, const uint8_t *key_bytes, const int64_t *key_off, int64_t J, const int64_t *row_ptr,
+                           const int64_t *samples, const int32_t *cov);
 
 /* AnnoyIndex.get_n_items()                                     morna.py:1174 */
 int64_t morna_get_n_items(const morna_index *h);

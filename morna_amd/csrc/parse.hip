@@ -394,6 +394,64 @@ int morna_lines_load(const char *path, int64_t *tag_out, morna_lines **out)
     return MORNA_OK;
 }
 
+// Inverse of the parser, for benchmarks and round-trip tests (no counterpart in the reference): the given lines as an
+// intropolis text file -- chrom, start, end (the key's three words), strand, donor, acceptor, sample list, coverage list,
+// tab separated (tests/tiny_intropolis.tsv) -- gzipped when the path ends in ".gz" (level 1).
+int morna_write_intropolis(const char *path, const uint8_t *key_bytes, const int64_t *key_off, int64_t J, const int64_t *row_ptr,
+                           const int64_t *samples, const int32_t *cov)
+{
+    if (!path || J < 0 || (J > 0 && (!key_bytes || !key_off || !row_ptr || !samples || !cov))) {
+        set_error("write_intropolis: null argument");
+        return MORNA_E_INVALID;
+    }
+    const size_t plen = strlen(path);
+    const bool gz = plen > 3 && strcmp(path + plen - 3, ".gz") == 0;
+    gzFile zf = nullptr;
+    FILE *pf = nullptr;
+    if (gz) zf = gzopen(path, "wb1");
+    else pf = fopen(path, "wb");
+    if (!zf && !pf) {
+        set_error("Unable to open %s for writing", path);
+        return MORNA_E_IO;
+    }
+    if (zf) gzbuffer(zf, 1 << 20);
+    std::string line;
+    bool ok = true;
+    char num[24];
+    auto put_num = [&](long long v) {
+        int n = 0;
+        bool neg = v < 0;
+        unsigned long long u = neg ? 0ull - (unsigned long long)v : (unsigned long long)v;
+        do { num[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+        if (neg) line.push_back('-');
+        while (n) line.push_back(num[--n]);
+    };
+    for (int64_t j = 0; ok && j < J; j++) {
+        line.clear();
+        for (int64_t i = key_off[j]; i < key_off[j + 1]; i++) line.push_back(key_bytes[i] == ' ' ? '\t' : (char)key_bytes[i]);
+        line.append("\t+\tGT\tAG\t");
+        for (int64_t t = row_ptr[j]; t < row_ptr[j + 1]; t++) {
+            if (t > row_ptr[j]) line.push_back(',');
+            put_num(samples[t]);
+        }
+        line.push_back('\t');
+        for (int64_t t = row_ptr[j]; t < row_ptr[j + 1]; t++) {
+            if (t > row_ptr[j]) line.push_back(',');
+            put_num(cov[t]);
+        }
+        line.push_back('\n');
+        if (zf) ok = gzwrite(zf, line.data(), (unsigned)line.size()) == (int)line.size();
+        else ok = fwrite(line.data(), 1, line.size(), pf) == line.size();
+    }
+    if (zf) ok = (gzclose(zf) == Z_OK) && ok;
+    if (pf) ok = (fclose(pf) == 0) && ok;
+    if (!ok) {
+        set_error("short write to %s", path);
+        return MORNA_E_IO;
+    }
+    return MORNA_OK;
+}
+
 int morna_stage_lines(morna_index *h, const morna_lines *L)
 {
     if (!h || !L) {

@@ -255,3 +255,38 @@ def test_division_by_count_route_quick(tmp_path):
     r = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 differ" in r.stdout.splitlines()[0]
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_write_intropolis_round_trip(tmp_path, gz):
+    """morna_write_intropolis (bench / test utility) writes what morna_parse_intropolis reads back: same kept lines,
+    first-seen ids, coverages and idf as the Python pre-pass over the same arrays."""
+    from morna_amd._lib import check, lib, ptr
+    rng = np.random.default_rng(12)
+    J, n_samples = 200, 500
+    keys = ["chr%d %d %d" % (rng.integers(1, 23), rng.integers(1, 10**8), rng.integers(1, 10**8)) for _ in range(J)]
+    keys[17] = keys[3]
+    rp, s, c = [0], [], []
+    for j in range(J):
+        ids = np.sort(rng.choice(n_samples, size=int(rng.integers(1, 60)), replace=False)) + 1
+        s += ids.tolist()
+        c += rng.integers(1, 5000, size=len(ids)).tolist()
+        rp.append(len(s))
+    rp, s, c = np.array(rp, np.int64), np.array(s, np.int64), np.array(c, np.int32)
+    kb = [k.encode("ascii") for k in keys]
+    key_off = np.zeros(J + 1, np.int64)
+    key_off[1:] = np.cumsum([len(k) for k in kb])
+    key_bytes = np.frombuffer(b"".join(kb), np.uint8)
+    path = str(tmp_path / ("w.tsv.gz" if gz else "w.tsv"))
+    check(lib().morna_write_intropolis(path.encode(), ptr(key_bytes), ptr(key_off), J, ptr(rp), ptr(s), ptr(c)))
+    import gzip
+    with (gzip.open(path, "rt") if gz else open(path)) as fh:
+        first = fh.readline().rstrip("\n").split("\t")
+    assert " ".join(first[:3]) == keys[0] and len(first) == 8
+    assert first[-2] == ",".join(str(x) for x in s[:rp[1]]) and first[-1] == ",".join(str(x) for x in c[:rp[1]])
+    got = mindex.ParsedLines(path, n_samples, 10)
+    want = mindex.prepare_csr(keys, rp, s, c, n_samples, 10)
+    a = got.arrays()
+    for k in ("key_bytes", "key_off", "row_ptr", "ids", "cov", "ext_ids"):
+        assert a[k].tolist() == np.asarray(want[k]).tolist(), k
+    assert a["idf"].tobytes() == want["idf"].tobytes()
