@@ -84,16 +84,18 @@ def main():
             staged_bytes = sum(arrs[k].nbytes for k in ("key_bytes", "key_off", "row_ptr", "ids", "cov", "idf"))
             # the same copy with the two big arrays page-locked first (hipHostRegister): what a caller that keeps its
             # parse buffers pinned would see; the registration itself is timed apart
-            import torch
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
+            hip.hipHostUnregister.argtypes = [C.c_void_p]
             t0 = time.perf_counter()
-            pinned = [torch.cuda.cudart().cudaHostRegister(arrs[k].ctypes.data, arrs[k].nbytes, 0) for k in ("ids", "cov")]
+            pinned = [hip.hipHostRegister(arrs[k].ctypes.data, arrs[k].nbytes, 0) for k in ("ids", "cov")]
             t_pin = time.perf_counter() - t0
             t0 = time.perf_counter()
             parsed.stage(idx)
             idx.synchronize()
             t_stage_pinned = time.perf_counter() - t0
             for k in ("ids", "cov"):
-                torch.cuda.cudart().cudaHostUnregister(arrs[k].ctypes.data)
+                hip.hipHostUnregister(arrs[k].ctypes.data)
             t0 = time.perf_counter()
             idx.build_features(parsed.n_items)
             idx.synchronize()
