@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmorna_hip.so")
+LIB_PATH = os.environ.get("MORNA_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmorna_hip.so")   # MORNA_LIB: an experimental build
 
 OK, E_INVALID, E_HIP, E_STATE, E_RANGE, E_IO, E_EMPTY = 0, -1, -2, -3, -4, -5, -6
 

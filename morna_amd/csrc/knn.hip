@@ -189,6 +189,7 @@ __global__ __launch_bounds__(Q_THREADS) void query_traverse_kernel(QueryParams P
 // nq * K >> N.  Queries are the A side (m), rows the B side (n): 32 lanes hold 32 consecutive rows of one query, so
 // the result goes out in 128-byte runs.  qrow: row of Q16 that holds query q (by-item queries point into the
 // matrix's own image), or null for the identity.
+template <int BR, int BK, int NS>   // rows of the matrix per workgroup tile, halfs per K-step, stages in flight (mm16.hpp)
 __global__ __launch_bounds__(MM16_THREADS) void query_scores_kernel(const _Float16 *__restrict__ X16, int64_t n_items, int32_t dpad,
                                                                     const _Float16 *__restrict__ Q16,
                                                                     const int32_t *__restrict__ qrow, int32_t nq,
@@ -196,13 +197,14 @@ __global__ __launch_bounds__(MM16_THREADS) void query_scores_kernel(const _Float
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int32_t s_qrow[MM16_TILE];
+    constexpr int NB = BR / 128;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const int wm = w >> 1, wn = w & 1;
     // workgroup b runs on XCD b % 8: an XCD takes every 8th row tile and walks that tile's query tiles back to back,
     // so the row tile comes from HBM once and then from that XCD's L2
     const int n_ct = (nq + MM16_TILE - 1) / MM16_TILE;
     const int64_t row_tile = (int64_t)((blockIdx.x >> 3) / n_ct) * 8 + (blockIdx.x & 7);
-    const int64_t r0 = row_tile * MM16_TILE;
+    const int64_t r0 = row_tile * BR;
     const int c0 = (int)((blockIdx.x >> 3) % n_ct) * MM16_TILE;
     if (r0 >= n_items) return;
     if (tid < MM16_TILE) {
@@ -210,19 +212,22 @@ __global__ __launch_bounds__(MM16_THREADS) void query_scores_kernel(const _Float
         s_qrow[tid] = qrow ? qrow[q] : q;
     }
     __syncthreads();
-    mm16_f32x16 acc[2];
-    mm16_tile(X16, Q16, dpad, smem, [&](int rt) { return r0 + rt < n_items ? r0 + rt : n_items - 1; },
-              [&](int rt) { return (int64_t)s_qrow[rt]; }, acc);
+    mm16_f32x16 acc[NB][2];
+    mm16_tile<BR, BK, NS>(X16, Q16, dpad, smem, [&](int rt) { return r0 + rt < n_items ? r0 + rt : n_items - 1; },
+                          [&](int rt) { return (int64_t)s_qrow[rt]; }, acc);
     const int lr = lane & 31, lh = lane >> 5;
-    const int64_t r = r0 + wm * 32 + lr;
-    if (r < n_items) {
 #pragma unroll
-        for (int tn = 0; tn < 2; tn++)
+    for (int tb = 0; tb < NB; tb++) {
+        const int64_t r = r0 + wm * 32 * NB + tb * 32 + lr;
+        if (r < n_items) {
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int q = c0 + wn * 64 + tn * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (q < nq) scores[(int64_t)q * n_items + r] = acc[tn][e];
-            }
+            for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int q = c0 + wn * 64 + tn * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (q < nq) scores[(int64_t)q * n_items + r] = acc[tb][tn][e];
+                }
+        }
     }
 }
 
@@ -509,11 +514,11 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
                 } else {
                     P.qn16 = P.xn16; P.qe16 = P.xe16; P.qscale = P.xscale;
                 }
-                const unsigned n_rt = (unsigned)((N + MM16_TILE - 1) / MM16_TILE), n_ct = (unsigned)((nb + MM16_TILE - 1) / MM16_TILE);
-                HIP_TRY(hipFuncSetAttribute((const void *)query_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MM16_LDS));
+                const unsigned n_ct = (unsigned)((nb + MM16_TILE - 1) / MM16_TILE), n_rt = (unsigned)((N + 127) / 128);
                 ScopedTimer tf(h, MORNA_T_QUERY_FILTER, 2 * (int64_t)nb * N * h->dpad);   // "bytes" = executed flops
-                hipLaunchKernelGGL(query_scores_kernel, dim3(8u * ((n_rt + 7) / 8) * n_ct), dim3(MM16_THREADS), MM16_LDS, h->stream,
-                                   P.X16, N, h->dpad, q16, qrow, (int32_t)nb, scores);
+                HIP_TRY(hipFuncSetAttribute((const void *)query_scores_kernel<128, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, MM16_LDS));
+                hipLaunchKernelGGL((query_scores_kernel<128, 64, 2>), dim3(8u * ((n_rt + 7) / 8) * n_ct), dim3(MM16_THREADS), MM16_LDS,
+                                   h->stream, P.X16, N, h->dpad, q16, qrow, (int32_t)nb, scores);
                 P.scores = scores;
             }
             // beside the contraction (matrix cores, LDS) the traversal is a latency chain on one wave per query: it

@@ -134,10 +134,11 @@ __global__ __launch_bounds__(SM_THREADS) void split_mm_kernel(
     // the contraction (mm16.hpp): hyperplanes are the A side (m) and the rows the B side (n), so the result has a
     // row of X on the lane and the epilogue's look-ups and side bytes of a wave run along consecutive rows; rows
     // past the end repeat the last one: their products are never looked up
-    f32x16 acc[2];
-    mm16_tile(X16, H16, dpad, smem,
-              [&](int rt) { return r0 + rt < n_items ? r0 + rt : n_items - 1; },
-              [&](int rt) { return (int64_t)(c0 + rt < n_tasks ? c0 + rt : n_tasks - 1); }, acc);
+    f32x16 acc1[1][2];
+    mm16_tile<128, 64, 2>(X16, H16, dpad, smem,
+                   [&](int rt) { return r0 + rt < n_items ? r0 + rt : n_items - 1; },
+                   [&](int rt) { return (int64_t)(c0 + rt < n_tasks ? c0 + rt : n_tasks - 1); }, acc1);
+    f32x16 (&acc)[2] = acc1[0];
     const int lr = lane & 31, lh = lane >> 5;
 
     // The result goes to LDS as C[hyperplane][row].  C/D layout of the 32x32 MFMA: n = lane & 31 (a row of X),
@@ -303,6 +304,7 @@ int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, co
                        (int64_t)n_tasks, h->dpad, h16.p, hn.p, hn.p + n_tasks, (float *)nullptr, amb_count);
     const unsigned n_rt = (unsigned)((N + SM_TILE - 1) / SM_TILE), n_ct = (unsigned)((n_tasks + SM_TILE - 1) / SM_TILE);
     const dim3 grid(8u * ((n_rt + 7) / 8) * n_ct);
+    static_assert(MM16_LDS_OF(128, 64, 2) == SM_TILE * SM_TILE * 4, "the slabs and the result tile share the dynamic LDS");
     HIP_TRY(hipFuncSetAttribute((const void *)split_mm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_TILE * SM_TILE * 4));
     hipLaunchKernelGGL(split_mm_kernel, grid, dim3(SM_THREADS), SM_TILE * SM_TILE * 4, h->stream, x16.p, xn.p, xn.p + 2 * N, N, h->dpad, h16.p, hn.p, hn.p + n_tasks, n_tasks, d_tasks,
                        row_task, row_pos, sm_eps(h->dpad), side, ones, amb_count, amb, (unsigned int)cap);
