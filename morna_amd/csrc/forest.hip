@@ -857,11 +857,13 @@ __host__ __device__ inline bool sides_stand(int attempt, int64_t n0, int64_t n1)
 // stable partition of one segment by side; one workgroup per node (PT threads: 1024 while nodes are large).
 // Launched right behind the split of every attempt, before the host has seen the counts: a node whose sides do
 // not stand is left alone (its next attempt, or the fallback, partitions it).
+// inv (may be null): inv[tree][item] = position of the item in the tree's permutation, kept current here -- what the
+// matrix-core split looks a row's node up with (one look-up per (row, tree), no separate inversion pass per level).
 template <int PT>
 __global__ __launch_bounds__(PT) void partition_kernel(const SplitTask *__restrict__ tasks, int64_t n_items,
                                                        const uint8_t *__restrict__ side,
                                                        const int32_t *__restrict__ ones, int32_t *__restrict__ perm,
-                                                       int32_t *__restrict__ tmp)
+                                                       int32_t *__restrict__ tmp, int32_t *__restrict__ inv)
 {
     __shared__ int s_w1[PT / WAVE];
     const SplitTask t = tasks[blockIdx.x];
@@ -904,7 +906,9 @@ __global__ __launch_bounds__(PT) void partition_kernel(const SplitTask *__restri
         for (int u = 0; u < PT_PER; u++)
             if (sd[u] >= 0) {
                 const int dst = sd[u] ? (n0 + run1 + r1) : (run0 + (rv - r1));
-                tmp[base + dst] = perm[base + pb + u];
+                const int32_t item = perm[base + pb + u];
+                tmp[base + dst] = item;
+                if (inv) inv[(int64_t)t.tree * n_items + item] = t.start + dst;
                 r1 += sd[u];
                 rv += 1;
             }
@@ -924,10 +928,13 @@ __global__ __launch_bounds__(PT) void partition_kernel(const SplitTask *__restri
     }
 }
 
-__global__ void iota_perm_kernel(int32_t *perm, int64_t n_items, int64_t total)
+__global__ void iota_perm_kernel(int32_t *perm, int32_t *inv, int64_t n_items, int64_t total)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) perm[i] = (int32_t)(i % n_items);
+    if (i < total) {
+        perm[i] = (int32_t)(i % n_items);
+        if (inv) inv[i] = (int32_t)(i % n_items);
+    }
 }
 
 // -------------------------------------------------------------- host driver
@@ -975,10 +982,15 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
     MORNA_TRY(d_cursor.alloc((size_t)n_buckets));
     // row-window form of the shallow levels: inverse permutation per tree
     ScratchRef<int32_t> row_task(h->scratch[16]), row_pos(h->scratch[17]), d_tree_first(h->scratch[18]);
+    // matrix-core split: position of every item in every tree's permutation, kept current by partition_kernel
+    static const bool mm_on = !(getenv("MORNA_SPLIT_MM") && atoi(getenv("MORNA_SPLIT_MM")) == 0);
+    ScratchRef<int32_t> inv(h->scratch[26]);
+    if (mm_on) MORNA_TRY(inv.alloc((size_t)n_trees * N));
+    int32_t *const inv_p = mm_on ? inv.p : nullptr;
     std::vector<int32_t> tree_first;
     {
         const int64_t total = (int64_t)n_trees * N;
-        hipLaunchKernelGGL(iota_perm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->perm.p, N, total);
+        hipLaunchKernelGGL(iota_perm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->perm.p, inv_p, N, total);
         HIP_TRY(hipGetLastError());
     }
 
@@ -1066,10 +1078,10 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 ScopedTimer tm(h, MORNA_T_PARTITION, 0);
                 if (level_rows >= (int64_t)A * 2048)
                     hipLaunchKernelGGL(partition_kernel<1024>, dim3((unsigned)A), dim3(1024), 0, h->stream, d_tasks.p, N, side.p,
-                                       d_ones.p, h->perm.p, tmp.p);
+                                       d_ones.p, h->perm.p, tmp.p, inv_p);
                 else
                     hipLaunchKernelGGL(partition_kernel<256>, dim3((unsigned)A), dim3(256), 0, h->stream, d_tasks.p, N, side.p,
-                                       d_ones.p, h->perm.p, tmp.p);
+                                       d_ones.p, h->perm.p, tmp.p, inv_p);
             }
             h_ones.resize((size_t)A);
             if (hipGetLastError() != hipSuccess ||
@@ -1106,28 +1118,33 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             // contraction on the matrix cores (splitmm.hip): its cost grows with the nodes per tree (every row
             // meets every hyperplane), the chunk form's does not -- they meet near 64 nodes per tree.
             // MORNA_SPLIT_MM=0 turns it off (row-window / chunk forms as before).
-            static const bool mm_on = !(getenv("MORNA_SPLIT_MM") && atoi(getenv("MORNA_SPLIT_MM")) == 0);
             const bool use_mm = mm_on && attempt == 0 && max_per_tree >= 1 && max_per_tree <= 32 &&
                                 rows * 2 >= (int64_t)n_trees * N;
             F_TRY(hipMemcpyAsync(d_tasks.p, tasks.data(), (size_t)A * sizeof(SplitTask), hipMemcpyHostToDevice, h->stream));
             // (d_ones is zeroed by the two_means kernel of the attempt, task by task: a hipMemsetAsync costs ~15 us of
             // idle device around its few microseconds)
             bool side_work = false;
-            if (use_mm || use_rw) {
-                // row -> (task, position) per tree, and, the first time, the fp16 image of the rows: both depend only on
-                // the task list and the previous partition, not on this level's two_means, so they run on the side
-                // stream while two_means (a latency chain on few CUs at the shallow levels) has the main one
+            if (use_mm && !h->half_valid) {
+                // once per set of rows: their fp16 image, on the side stream while two_means (a latency chain on few CUs
+                // at the root level) has the main one.  Nothing else of the matrix-core split needs a side stream: a
+                // row's node is looked up through `inv`, which the partition of the previous level left current (round 1
+                // inverted the permutations in a kernel of its own per level, behind two event hand-overs of ~17 us each).
+                F_TRY(hipEventRecord(h->ev_fork, h->stream));
+                F_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+                if ((rc = split_mm_prepare_rows(h, h->stream2))) { cleanup(); return rc; }
+                F_TRY(hipEventRecord(h->ev_join, h->stream2));
+                side_work = true;
+            } else if (use_rw && !use_mm) {
+                // row-window form (MORNA_SPLIT_MM=0): row -> (task, position) per tree on the side stream
                 if ((rc = row_task.alloc((size_t)n_trees * N)) || (rc = row_pos.alloc((size_t)n_trees * N)) ||
                     (rc = d_tree_first.alloc((size_t)n_trees + 1))) { cleanup(); return rc; }
                 F_TRY(hipEventRecord(h->ev_fork, h->stream));
                 F_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-                if (use_rw && !use_mm)   // only the row-window kernel reads the per-tree task ranges
-                    F_TRY(hipMemcpyAsync(d_tree_first.p, tree_first.data(), ((size_t)n_trees + 1) * 4, hipMemcpyHostToDevice, h->stream2));
+                F_TRY(hipMemcpyAsync(d_tree_first.p, tree_first.data(), ((size_t)n_trees + 1) * 4, hipMemcpyHostToDevice, h->stream2));
                 if (rows != (int64_t)n_trees * N)   // rows outside every split node must read "no task"
                     F_TRY(hipMemsetAsync(row_task.p, 0xFF, (size_t)n_trees * N * 4, h->stream2));
                 hipLaunchKernelGGL(invert_kernel, dim3((unsigned)n_chunks), dim3(64), 0, h->stream2, d_tasks.p, A, n_chunks,
                                    h->perm.p, N, row_task.p, row_pos.p);
-                if (use_mm && (rc = split_mm_prepare_rows(h, h->stream2))) { cleanup(); return rc; }   // once per set of rows
                 F_TRY(hipEventRecord(h->ev_join, h->stream2));
                 side_work = true;
             }
@@ -1182,7 +1199,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             if (side_work) F_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
             if (use_mm) {
                 ScopedTimer tm(h, MORNA_T_SPLIT, 4 * (int64_t)D * (rows + A));
-                if ((rc = split_mm_level(h, d_tasks.p, A, hp_level, row_task.p, row_pos.p, seed, side.p, d_ones.p))) {
+                if ((rc = split_mm_level(h, d_tasks.p, A, hp_level, inv.p, seed, side.p, d_ones.p))) {
                     cleanup();
                     return rc;
                 }

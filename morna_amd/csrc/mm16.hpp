@@ -170,12 +170,12 @@ __device__ inline void mm16_tile(const _Float16 *__restrict__ B16, const _Float1
 }
 
 // 16 waves (1024 threads), 256 x 256 tile, 64 x 64 per wave, ONE chain of dpad products (the register file holds no
-// second set of accumulators at four waves per SIMD); smem: 2 stages of 512 rows
-template <int BK, typename BRow, typename ARow>
+// second set of accumulators at four waves per SIMD); smem: NS stages of 512 rows of BK halfs
+template <int BK, int NS, typename BRow, typename ARow>
 __device__ inline void mm16_tile_256x256(const _Float16 *__restrict__ B16, const _Float16 *__restrict__ A16, int32_t dpad,
                                          unsigned char *smem, BRow b_row, ARow a_row, mm16_f32x16 (&acc)[2][2])
 {
-    mm16_core<4, 4, 2, BK, 2, 1>(B16, A16, dpad, smem, b_row, a_row, acc);
+    mm16_core<4, 4, 2, BK, NS, 1>(B16, A16, dpad, smem, b_row, a_row, acc);
 }
 
 // EACC of the callers' bound: |sum y_i g_i (as computed) - exact| <= EACC |y| |g| for two chains of dpad / 2 products,

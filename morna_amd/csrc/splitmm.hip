@@ -89,126 +89,159 @@ __global__ __launch_bounds__(256) void rows_to_half_kernel(const float *__restri
 }
 
 // ---- the contraction with the side decision fused into its epilogue --------------------------------
-#define SM_TILE 128
-#define SM_THREADS 512           // 8 waves, each a 32 x 64 part of the tile; two workgroups per CU (78 KB of LDS each)
-#define SM_BK 64                 // halfs per K step
 #define SM_OPEN 1536             // open pairs a tile keeps in LDS (12 KB; ~500 expected of 16384 at the root level)
 
-__global__ __launch_bounds__(SM_THREADS) void split_mm_kernel(
+// BIG = false: 128 rows x 128 hyperplanes per workgroup, 8 waves, two accumulation chains; two workgroups per CU.
+// BIG = true : 256 x 256, 16 waves, one chain (mm16.hpp): half the operand bytes delivered to LDS per product -- the
+//              loop is bound by those deliveries -- for levels with enough hyperplane tiles to fill the chip evenly.
+//              Its bound (EACC for one chain of dpad products) is wider, so it leaves more pairs open; the sides written
+//              are the same either way.
+template <bool BIG>
+__global__ __launch_bounds__(BIG ? 1024 : 512) void split_mm_kernel(
     const _Float16 *__restrict__ X16, const float *__restrict__ xn, const float *__restrict__ xe, int64_t n_items, int32_t dpad,
     const _Float16 *__restrict__ H16, const float *__restrict__ hn, const float *__restrict__ he, int32_t n_tasks,
-    const SplitTask *__restrict__ tasks, const int32_t *__restrict__ row_task, const int32_t *__restrict__ row_pos,
+    const SplitTask *__restrict__ tasks, const int32_t *__restrict__ inv /* [tree][item] position in the tree's permutation */,
     float eps, uint8_t *__restrict__ side, int32_t *__restrict__ ones, unsigned int *__restrict__ amb_count,
     int2 *__restrict__ amb, unsigned int amb_cap)
 {
-    // 64 KB: during the contraction two buffers of two operand slabs ([128 rows][64 halfs] each), afterwards
-    // the 128 x 128 result
+    constexpr int ROWS = BIG ? 256 : 128, COLS = ROWS, THREADS = BIG ? 1024 : 512;
+    // dynamic LDS: during the contraction the stages of operand slabs, afterwards the result, 128 hyperplanes x ROWS rows at
+    // a time (BIG: the two halves of the hyperplane tile in turn)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *Cs = (float *)smem;                    // result      [128 hyperplanes][128 rows]
-    __shared__ int s_ones[SM_TILE], s_tree[SM_TILE], s_start[SM_TILE];
-    __shared__ float s_hn[SM_TILE], s_he[SM_TILE];
+    float *Cs = (float *)smem;
+    __shared__ int s_ones[COLS], s_tree[COLS], s_start[COLS], s_end[COLS];
+    __shared__ float s_hn[COLS], s_he[COLS];
     __shared__ int2 s_open[SM_OPEN];   // pairs this tile's filter left open
     __shared__ int s_nopen;
     __shared__ unsigned int s_obase;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
-    const int wm = w >> 1, wn = w & 1;   // the wave's part of the tile: rows wm * 32 .. +31, columns wn * 64 .. +63
     // Workgroup b runs on XCD b % 8.  An XCD takes every 8th row tile and walks that tile's hyperplane tiles
     // back to back: the row tile (786 KB at D = 3000) is fetched from HBM once and then served by that XCD's
     // L2; the level's hyperplanes (a few MB) stay in the Infinity Cache for everybody.
-    const int n_ct = (n_tasks + SM_TILE - 1) / SM_TILE;
+    const int n_ct = (n_tasks + COLS - 1) / COLS;
     const int64_t row_tile = (int64_t)((blockIdx.x >> 3) / n_ct) * 8 + (blockIdx.x & 7);
-    const int64_t r0 = row_tile * SM_TILE;
-    const int c0 = (int)((blockIdx.x >> 3) % n_ct) * SM_TILE;
+    const int64_t r0 = row_tile * ROWS;
+    const int c0 = (int)((blockIdx.x >> 3) % n_ct) * COLS;
     if (r0 >= n_items) return;
 
-    if (tid < SM_TILE) {
+    if (tid < COLS) {
         const int col = c0 + tid < n_tasks ? c0 + tid : n_tasks - 1;
         const SplitTask t = tasks[col];
         s_ones[tid] = 0;
         if (tid == 0) s_nopen = 0;
         s_tree[tid] = t.tree;
         s_start[tid] = t.start;
+        s_end[tid] = t.start + t.count;
         s_hn[tid] = hn[col];
         s_he[tid] = he[col];
     }
     // the contraction (mm16.hpp): hyperplanes are the A side (m) and the rows the B side (n), so the result has a
     // row of X on the lane and the epilogue's look-ups and side bytes of a wave run along consecutive rows; rows
     // past the end repeat the last one: their products are never looked up
-    f32x16 acc1[1][2];
-    mm16_tile<128, 64, 2>(X16, H16, dpad, smem,
-                   [&](int rt) { return r0 + rt < n_items ? r0 + rt : n_items - 1; },
-                   [&](int rt) { return (int64_t)(c0 + rt < n_tasks ? c0 + rt : n_tasks - 1); }, acc1);
-    f32x16 (&acc)[2] = acc1[0];
+    constexpr int NB = BIG ? 2 : 1;
+    f32x16 acc[NB][2];
+    auto b_row = [&](int rt) { return r0 + rt < n_items ? r0 + rt : n_items - 1; };
+    auto a_row = [&](int rt) { return (int64_t)(c0 + rt < n_tasks ? c0 + rt : n_tasks - 1); };
+    if constexpr (BIG) mm16_tile_256x256<64, 2>(X16, H16, dpad, smem, b_row, a_row, acc);   // (4 stages of 32 halfs, three deliveries in flight: 0.62 / 0.73 ms against 0.57 / 0.66 at C3)
+    else mm16_tile<128, 64, 2>(X16, H16, dpad, smem, b_row, a_row, acc);
     const int lr = lane & 31, lh = lane >> 5;
+    const int wm = BIG ? w >> 2 : w >> 1, wn = BIG ? w & 3 : w & 1;   // the wave's part of the tile: B rows wm * 32 NB .., A rows wn * 64 ..
 
-    // The result goes to LDS as C[hyperplane][row].  C/D layout of the 32x32 MFMA: n = lane & 31 (a row of X),
-    // m = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (a hyperplane = a task of the level).
-#pragma unroll
-    for (int tn = 0; tn < 2; tn++)
-#pragma unroll
-        for (int e = 0; e < 16; e++)
-            Cs[(wn * 64 + tn * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * SM_TILE + wm * 32 + lr] = acc[tn][e];
-    __syncthreads();
-
-    // A row needs ONE entry per tree: that of its node.  A wave takes 64 consecutive rows and one tree at a
-    // time: the task look-up, the position look-up and the side bytes all run along consecutive rows.
-    const int c_hi = (c0 + SM_TILE < n_tasks ? c0 + SM_TILE : n_tasks);   // tasks [c0, c_hi) are this tile's
-    const int t_first = s_tree[0], t_last = s_tree[c_hi - 1 - c0];
-    const int64_t row = r0 + (tid & (SM_TILE - 1));
+    const int64_t row = r0 + (tid & (ROWS - 1));
     const bool row_ok = row < n_items;
     // bound of a pair = (EACC |y| + |d|) |g| + (|y| + |d|) |f|, 0.5 % of slack for its own roundings
     const float xn_r = xn[row_ok ? row : 0], xe_r = xe[row_ok ? row : 0];
     const float xa = (eps * xn_r + xe_r) * 1.005f, xb = (xn_r + xe_r) * 1.005f;
-    constexpr int EU = 8, TSTEP = SM_THREADS / SM_TILE;   // trees per batch and thread; trees between a thread's steps
-    for (int tb = t_first + (tid >> 7); tb <= t_last; tb += EU * TSTEP) {
-        // the look-ups of a batch are issued together: each one is a dependent chain of two loads
-        int a[EU], pos[EU];
 #pragma unroll
-        for (int u = 0; u < EU; u++) {
-            const int tr = tb + u * TSTEP;
-            a[u] = (row_ok && tr <= t_last) ? row_task[(int64_t)tr * n_items + row] : -1;
+    for (int half = 0; half < COLS / 128; half++) {
+        // The result goes to LDS as C[hyperplane][row], 128 hyperplanes at a time.  C/D layout of the 32x32 MFMA: n = lane & 31
+        // (a row of X), m = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (a hyperplane = a task of the level).
+        if (half) __syncthreads();   // the first half has been looked up
+        if ((wn >> 1) == half) {
+#pragma unroll
+            for (int tb = 0; tb < NB; tb++)
+#pragma unroll
+                for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        Cs[((wn & 1) * 64 + tn * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * ROWS + wm * 32 * NB + tb * 32 + lr] = acc[tb][tn][e];
         }
+        __syncthreads();
+        const int c_lo = c0 + half * 128;
+        if (c_lo >= n_tasks) break;   // uniform
+        // A row needs ONE entry per tree: that of its node.  A wave takes 64 consecutive rows and one tree at a
+        // time: the task look-up, the position look-up and the side bytes all run along consecutive rows.
+        const int c_hi = (c_lo + 128 < n_tasks ? c_lo + 128 : n_tasks);   // tasks [c_lo, c_hi) are this pass's
+        const int t_first = s_tree[c_lo - c0], t_last = s_tree[c_hi - 1 - c0];
+        constexpr int EU = BIG ? 4 : 8, TSTEP = THREADS / ROWS;   // trees per batch and thread (BIG: the other half of the result is still in registers); trees between a thread's steps
+        for (int tb = t_first + tid / ROWS; tb <= t_last; tb += EU * TSTEP) {
+            // the look-ups of a batch are issued together: where the row stands in each tree's permutation
+            int a[EU], pos[EU], pp[EU];
 #pragma unroll
-        for (int u = 0; u < EU; u++) {
-            const int tr = tb + u * TSTEP;
-            pos[u] = (a[u] >= c0 && a[u] < c_hi) ? row_pos[(int64_t)tr * n_items + row] : 0;
-        }
+            for (int u = 0; u < EU; u++) {
+                const int tr = tb + u * TSTEP;
+                pp[u] = (row_ok && tr <= t_last) ? inv[(int64_t)tr * n_items + row] : -1;
+            }
 #pragma unroll
-        for (int u = 0; u < EU; u++) {
-            const int tr = tb + u * TSTEP;
-            const bool mine = a[u] >= c0 && a[u] < c_hi;
-            const int cl = mine ? a[u] - c0 : 0;
-            const float c = Cs[cl * SM_TILE + (tid & (SM_TILE - 1))];   // bank = row: no conflict whatever the nodes are
-            // false for NaN and for rows / hyperplanes that could not be scaled (norm = +inf)
-            const bool decided = mine && fabsf(c) > xa * s_hn[cl] + xb * s_he[cl];
-            const bool one = decided && c > 0.f;
-            if (decided) side[(int64_t)tr * n_items + s_start[cl] + pos[u]] = (uint8_t)one;
-            // right-side counts: one LDS atomic per wave when its rows share the node (the rule at shallow levels)
-            const uint64_t mm = __ballot(mine);
-            if (mm) {
-                const int cl0 = __builtin_amdgcn_readlane(cl, __builtin_ctzll(mm));
-                const uint64_t onem = __ballot(one);
-                if (__ballot(mine && cl != cl0) == 0) {
-                    if (onem && lane == __builtin_ctzll(mm)) atomicAdd(&s_ones[cl0], (int)__builtin_popcountll(onem));
-                } else if (one) {
-                    atomicAdd(&s_ones[cl], 1);
+            for (int u = 0; u < EU; u++) {
+                // the node of the row in tree tr: among the tree's tasks in this tile (sorted by start), the one whose
+                // segment holds the position; none: the row sits in a leaf, or in a node of another tile
+                const int tr = tb + u * TSTEP;
+                a[u] = -1;
+                pos[u] = 0;
+                // (the tree is the same for the whole wave: its tasks in the tile are found with one ballot per 64 slots,
+                // and every lane counts the starts that do not exceed its position -- independent LDS broadcasts, no chain)
+                int lo = -1, n_t = 0;
+#pragma unroll
+                for (int k = 0; k < COLS / WAVE; k++) {
+                    const uint64_t mk = __ballot(c0 + k * WAVE + lane < n_tasks && s_tree[k * WAVE + lane] == tr);
+                    if (mk && lo < 0) lo = k * WAVE + (int)__builtin_ctzll(mk);
+                    n_t += (int)__builtin_popcountll(mk);
+                }
+                int before = 0;
+                for (int j = 0; j < n_t; j++) before += s_start[lo + j] <= pp[u] ? 1 : 0;
+                if (pp[u] >= 0 && before > 0 && pp[u] < s_end[lo + before - 1]) {
+                    a[u] = c0 + lo + before - 1;
+                    pos[u] = pp[u] - s_start[lo + before - 1];
                 }
             }
-            // open pairs are collected in LDS: all workgroups adding to the ONE global counter pair by pair (or
-            // wave by wave) is what the kernel would otherwise wait for (~350 M same-address atomics per second)
-            const bool open = mine && !decided;
-            const uint64_t om = __ballot(open);
-            if (om) {
-                int base = 0;
-                if (lane == __builtin_ctzll(om)) base = atomicAdd(&s_nopen, (int)__builtin_popcountll(om));
-                base = __builtin_amdgcn_readlane(base, __builtin_ctzll(om));
-                const int idx = base + (int)__builtin_popcountll(om & ((1ull << lane) - 1ull));
-                if (open) {
-                    if (idx < SM_OPEN) {
-                        s_open[idx] = make_int2((int)row, a[u]);
-                    } else {   // more than the LDS list holds: straight to the global list
-                        const unsigned int g = atomicAdd(amb_count, 1u);
-                        if (g < amb_cap) amb[g] = make_int2((int)row, a[u]);
+#pragma unroll
+            for (int u = 0; u < EU; u++) {
+                const int tr = tb + u * TSTEP;
+                const bool mine = a[u] >= c_lo && a[u] < c_hi;
+                const int cl = mine ? a[u] - c0 : 0;   // index into the tile's task tables
+                const float c = Cs[(mine ? a[u] - c_lo : 0) * ROWS + (tid & (ROWS - 1))];   // bank = row: no conflict whatever the nodes are
+                // false for NaN and for rows / hyperplanes that could not be scaled (norm = +inf)
+                const bool decided = mine && fabsf(c) > xa * s_hn[cl] + xb * s_he[cl];
+                const bool one = decided && c > 0.f;
+                if (decided) side[(int64_t)tr * n_items + s_start[cl] + pos[u]] = (uint8_t)one;
+                // right-side counts: one LDS atomic per wave when its rows share the node (the rule at shallow levels)
+                const uint64_t mm = __ballot(mine);
+                if (mm) {
+                    const int cl0 = __builtin_amdgcn_readlane(cl, __builtin_ctzll(mm));
+                    const uint64_t onem = __ballot(one);
+                    if (__ballot(mine && cl != cl0) == 0) {
+                        if (onem && lane == __builtin_ctzll(mm)) atomicAdd(&s_ones[cl0], (int)__builtin_popcountll(onem));
+                    } else if (one) {
+                        atomicAdd(&s_ones[cl], 1);
+                    }
+                }
+                // open pairs are collected in LDS: all workgroups adding to the ONE global counter pair by pair (or
+                // wave by wave) is what the kernel would otherwise wait for (~350 M same-address atomics per second)
+                const bool open = mine && !decided;
+                const uint64_t om = __ballot(open);
+                if (om) {
+                    int base = 0;
+                    if (lane == __builtin_ctzll(om)) base = atomicAdd(&s_nopen, (int)__builtin_popcountll(om));
+                    base = __builtin_amdgcn_readlane(base, __builtin_ctzll(om));
+                    const int idx = base + (int)__builtin_popcountll(om & ((1ull << lane) - 1ull));
+                    if (open) {
+                        if (idx < SM_OPEN) {
+                            s_open[idx] = make_int2((int)row, a[u]);
+                        } else {   // more than the LDS list holds: straight to the global list
+                            const unsigned int g = atomicAdd(amb_count, 1u);
+                            if (g < amb_cap) amb[g] = make_int2((int)row, a[u]);
+                        }
                     }
                 }
             }
@@ -219,17 +252,17 @@ __global__ __launch_bounds__(SM_THREADS) void split_mm_kernel(
         const int n_open = s_nopen < SM_OPEN ? s_nopen : SM_OPEN;
         if (tid == 0 && n_open) s_obase = atomicAdd(amb_count, (unsigned int)n_open);
         __syncthreads();
-        for (int i = tid; i < n_open; i += SM_THREADS)
+        for (int i = tid; i < n_open; i += THREADS)
             if (s_obase + i < amb_cap) amb[s_obase + i] = s_open[i];
     }
     __syncthreads();
-    if (tid < SM_TILE && c0 + tid < n_tasks && s_ones[tid]) atomicAdd(&ones[c0 + tid], s_ones[tid]);
+    if (tid < COLS && c0 + tid < n_tasks && s_ones[tid]) atomicAdd(&ones[c0 + tid], s_ones[tid]);
 }
 
 // ---- the pairs the filter left open: canonical fp32 dot, one wave per pair ------------------------
 __global__ __launch_bounds__(256) void split_amb_kernel(const float *__restrict__ X, int64_t n_items, int32_t dpad,
                                                         const SplitTask *__restrict__ tasks,
-                                                        const int32_t *__restrict__ row_pos, uint32_t seed,
+                                                        const int32_t *__restrict__ inv, uint32_t seed,
                                                         const float *__restrict__ hp,
                                                         const unsigned int *__restrict__ amb_count,
                                                         const int2 *__restrict__ amb, unsigned int amb_cap,
@@ -245,7 +278,7 @@ __global__ __launch_bounds__(256) void split_amb_kernel(const float *__restrict_
         const float d = wave_dot((const float4 *)(X + (int64_t)pr.x * dpad), (const float4 *)(hp + (int64_t)t.slot * dpad),
                                  nvec, lane);
         if (lane == 0) {
-            const int pos = row_pos[(int64_t)t.tree * n_items + pr.x];
+            const int pos = inv[(int64_t)t.tree * n_items + pr.x] - t.start;
             const uint32_t nseed = node_seed(seed, (uint32_t)t.tree, (uint32_t)t.level, (uint32_t)t.start, (uint32_t)t.attempt);
             // Angular::side: dot != 0 ? dot > 0 : coin flip
             const int s = d != 0.f ? (d > 0.f) : pos_flip(nseed, (uint32_t)pos);
@@ -283,7 +316,7 @@ int split_mm_convert_rows(morna_index *h, const float *src, int64_t rows, _Float
 }
 
 int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, const float *hp_level,
-                   const int32_t *row_task, const int32_t *row_pos, uint32_t seed, uint8_t *side, int32_t *ones)
+                   const int32_t *inv, uint32_t seed, uint8_t *side, int32_t *ones)
 {
     const int64_t N = h->n_items;
     ScratchRef<_Float16> x16(h->scratch[19]), h16(h->scratch[21]);
@@ -302,14 +335,26 @@ int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, co
     // the open-pair counter is reset by the kernel that converts the level's hyperplanes (same stream, just before)
     hipLaunchKernelGGL(rows_to_half_kernel, dim3((unsigned)((n_tasks + 3) / 4)), dim3(256), 0, h->stream, hp_level,
                        (int64_t)n_tasks, h->dpad, h16.p, hn.p, hn.p + n_tasks, (float *)nullptr, amb_count);
-    const unsigned n_rt = (unsigned)((N + SM_TILE - 1) / SM_TILE), n_ct = (unsigned)((n_tasks + SM_TILE - 1) / SM_TILE);
-    const dim3 grid(8u * ((n_rt + 7) / 8) * n_ct);
-    static_assert(MM16_LDS_OF(128, 64, 2) == SM_TILE * SM_TILE * 4, "the slabs and the result tile share the dynamic LDS");
-    HIP_TRY(hipFuncSetAttribute((const void *)split_mm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_TILE * SM_TILE * 4));
-    hipLaunchKernelGGL(split_mm_kernel, grid, dim3(SM_THREADS), SM_TILE * SM_TILE * 4, h->stream, x16.p, xn.p, xn.p + 2 * N, N, h->dpad, h16.p, hn.p, hn.p + n_tasks, n_tasks, d_tasks,
-                       row_task, row_pos, sm_eps(h->dpad), side, ones, amb_count, amb, (unsigned int)cap);
+    // 256 x 256 tiles once the level has hyperplane tiles enough for them to fill the chip in even rounds (MORNA_SPLIT_BIG=0:
+    // the 128 x 128 form everywhere)
+    static const bool big_on = !(getenv("MORNA_SPLIT_BIG") && atoi(getenv("MORNA_SPLIT_BIG")) == 0);
+    if (big_on && n_tasks >= 1024) {
+        const unsigned n_rt = (unsigned)((N + 255) / 256), n_ct = (unsigned)((n_tasks + 255) / 256);
+        const float eps1 = (4.f * (float)h->dpad + 2.f) * 5.9604645e-8f + 4.1e-6f;   // EACC for ONE chain of dpad products
+        HIP_TRY(hipFuncSetAttribute((const void *)split_mm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 256 * 4));
+        hipLaunchKernelGGL(split_mm_kernel<true>, dim3(8u * ((n_rt + 7) / 8) * n_ct), dim3(1024), 128 * 256 * 4, h->stream, x16.p, xn.p,
+                           xn.p + 2 * N, N, h->dpad, h16.p, hn.p, hn.p + n_tasks, n_tasks, d_tasks, inv, eps1, side, ones,
+                           amb_count, amb, (unsigned int)cap);
+    } else {
+        const unsigned n_rt = (unsigned)((N + 127) / 128), n_ct = (unsigned)((n_tasks + 127) / 128);
+        static_assert(MM16_LDS == 128 * 128 * 4, "the slabs and the result tile share the dynamic LDS");
+        HIP_TRY(hipFuncSetAttribute((const void *)split_mm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 4));
+        hipLaunchKernelGGL(split_mm_kernel<false>, dim3(8u * ((n_rt + 7) / 8) * n_ct), dim3(512), 128 * 128 * 4, h->stream, x16.p, xn.p,
+                           xn.p + 2 * N, N, h->dpad, h16.p, hn.p, hn.p + n_tasks, n_tasks, d_tasks, inv, sm_eps(h->dpad), side,
+                           ones, amb_count, amb, (unsigned int)cap);
+    }
     hipLaunchKernelGGL(split_amb_kernel, dim3((unsigned)(4 * h->n_cus)), dim3(256), 0, h->stream, h->X.p, N, h->dpad, d_tasks,
-                       row_pos, seed, hp_level, amb_count, amb, (unsigned int)cap, side, ones);
+                       inv, seed, hp_level, amb_count, amb, (unsigned int)cap, side, ones);
     HIP_TRY(hipGetLastError());
     // MORNA_DEBUG_OPEN=1: how many (row, tree) pairs the filter of this level left to the canonical dot (stderr;
     // costs a synchronisation, measurement only)

@@ -4,6 +4,10 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- before libmorna_hip.so is loaded: torch bundles its own libamdhip64, and a process that loads
+#                              the system one first (through our library) and torch's afterwards ends up with two HIP
+#                              runtimes, the second of which finds "No HIP GPUs" (seen when a test file that imports
+#                              torch only inside a test ran after GPU tests had used the library)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
