@@ -155,6 +155,8 @@ int morna_index_destroy(morna_index *h)
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->host_counts) (void)hipHostFree(h->host_counts);
+    if (h->host_out) (void)hipHostFree(h->host_out);
     hipStream_t s = h->stream, s2 = h->stream2;
     delete h;   // DevBuf destructors free HBM
     if (s2) (void)hipStreamDestroy(s2);

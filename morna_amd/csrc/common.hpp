@@ -121,6 +121,13 @@ struct morna_index {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;                 // side stream of the forest build (work that does not depend on two_means)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // right-side counts of a level, written by partition_kernel straight into page-locked host memory ((epoch << 32) |
+    // count per task): the host polls them instead of an event hand-over + copy + stream wait per level
+    unsigned long long *host_counts = nullptr;
+    size_t host_counts_cap = 0;
+    uint32_t count_epoch = 0;
+    uint8_t *host_out = nullptr;       // page-locked staging of query results
+    size_t host_out_cap = 0;
 
     // host staging of add_item() rows until build()
     std::vector<float> host_rows;  // [host_n][dim]

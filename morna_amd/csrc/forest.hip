@@ -859,16 +859,24 @@ __host__ __device__ inline bool sides_stand(int attempt, int64_t n0, int64_t n1)
 // not stand is left alone (its next attempt, or the fallback, partitions it).
 // inv (may be null): inv[tree][item] = position of the item in the tree's permutation, kept current here -- what the
 // matrix-core split looks a row's node up with (one look-up per (row, tree), no separate inversion pass per level).
+// host_counts (page-locked host memory, may be null): the task's right-side count goes there first thing, tagged with the
+// level's epoch, so that the host's bookkeeping for the next attempt or level runs while the partition does.
 template <int PT>
 __global__ __launch_bounds__(PT) void partition_kernel(const SplitTask *__restrict__ tasks, int64_t n_items,
                                                        const uint8_t *__restrict__ side,
                                                        const int32_t *__restrict__ ones, int32_t *__restrict__ perm,
-                                                       int32_t *__restrict__ tmp, int32_t *__restrict__ inv)
+                                                       int32_t *__restrict__ tmp, int32_t *__restrict__ inv,
+                                                       unsigned long long *__restrict__ host_counts, uint32_t epoch)
 {
     __shared__ int s_w1[PT / WAVE];
     const SplitTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const int n1 = ones[blockIdx.x], n0 = t.count - n1;
+    if (host_counts && tid == 0) {
+        // relaxed: the word carries everything the host reads (a release here would write back this CU's whole L2 share)
+        __hip_atomic_store(&host_counts[blockIdx.x], ((unsigned long long)epoch << 32) | (unsigned int)n1, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (!sides_stand(t.attempt, n0, n1)) return;   // uniform over the workgroup
     const int64_t base = (int64_t)t.tree * n_items + t.start;
     // PT_PER consecutive positions per thread and round: a round costs two barriers whatever it moves, and with one
@@ -1069,26 +1077,55 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
         // counts (d_tasks / d_ones as they are on the device).  The counts travel to the host on the side stream,
         // from the moment the split is done: the host's bookkeeping for the next attempt or level runs while the
         // partition does.
+        // Partition of the nodes whose sides stand, enqueued right behind the kernels that wrote the sides and their
+        // counts (d_tasks / d_ones as they are on the device).  The counts reach the host through page-locked memory
+        // that every partition workgroup writes before anything else, tagged with this call's epoch: the host polls the
+        // tags (no event hand-over, no copy, no stream wait) and prepares the next attempt or level while the partition runs.
         auto partition_and_fetch_counts = [&](int32_t A, int64_t level_rows) -> int {
-            if (hipEventRecord(h->ev_fork, h->stream) != hipSuccess || hipStreamWaitEvent(h->stream2, h->ev_fork, 0) != hipSuccess) {
-                set_error("forest build: event hand-over to the side stream failed");
-                return MORNA_E_HIP;
+            if ((size_t)A > h->host_counts_cap) {
+                if (hipStreamSynchronize(h->stream) != hipSuccess) return MORNA_E_HIP;   // nobody writes the old buffer any more
+                if (h->host_counts) (void)hipHostFree(h->host_counts);
+                h->host_counts = nullptr;
+                h->host_counts_cap = std::max<size_t>(4096, (size_t)A * 2);
+                if (hipHostMalloc((void **)&h->host_counts, h->host_counts_cap * 8, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+                    h->host_counts_cap = 0;
+                    set_error("forest build: hipHostMalloc of the count mailbox failed");
+                    return MORNA_E_HIP;
+                }
+                memset(h->host_counts, 0, h->host_counts_cap * 8);
             }
+            const uint32_t epoch = ++h->count_epoch ? h->count_epoch : ++h->count_epoch;   // never 0: the mailbox starts zeroed
             {
                 ScopedTimer tm(h, MORNA_T_PARTITION, 0);
                 if (level_rows >= (int64_t)A * 2048)
                     hipLaunchKernelGGL(partition_kernel<1024>, dim3((unsigned)A), dim3(1024), 0, h->stream, d_tasks.p, N, side.p,
-                                       d_ones.p, h->perm.p, tmp.p, inv_p);
+                                       d_ones.p, h->perm.p, tmp.p, inv_p, h->host_counts, epoch);
                 else
                     hipLaunchKernelGGL(partition_kernel<256>, dim3((unsigned)A), dim3(256), 0, h->stream, d_tasks.p, N, side.p,
-                                       d_ones.p, h->perm.p, tmp.p, inv_p);
+                                       d_ones.p, h->perm.p, tmp.p, inv_p, h->host_counts, epoch);
+            }
+            if (hipGetLastError() != hipSuccess) {
+                set_error("forest build: partition launch failed");
+                return MORNA_E_HIP;
             }
             h_ones.resize((size_t)A);
-            if (hipGetLastError() != hipSuccess ||
-                hipMemcpyAsync(h_ones.data(), d_ones.p, (size_t)A * 4, hipMemcpyDeviceToHost, h->stream2) != hipSuccess ||
-                hipStreamSynchronize(h->stream2) != hipSuccess) {
-                set_error("forest build: partition launch or count read-back failed");
-                return MORNA_E_HIP;
+            volatile unsigned long long *box = h->host_counts;
+            int64_t spins = 0;
+            for (int32_t a = 0; a < A; a++) {
+                unsigned long long v;
+                while ((uint32_t)((v = box[a]) >> 32) != epoch) {
+                    if (++spins > (int64_t)1 << 22) {
+                        // not there after a long while: let the stream say what happened (a failed launch, a fault), or
+                        // simply wait for a very large level the slow way
+                        if (hipStreamSynchronize(h->stream) != hipSuccess) {
+                            set_error("forest build: the partition kernel failed");
+                            return MORNA_E_HIP;
+                        }
+                        spins = 0;
+                    }
+                    __builtin_ia32_pause();
+                }
+                h_ones[(size_t)a] = (int32_t)(uint32_t)v;
             }
             return MORNA_OK;
         };

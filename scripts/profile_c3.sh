@@ -10,9 +10,9 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 STEPS=3; WARM=1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o p -- python3 "$REPO/bench.py" --steps $STEPS --warmup $WARM --no-cpu-baseline "$@" > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o p -- python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu-baseline "$@" > /dev/null 2> "$OUT/fetch.err"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -o p -- python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu-baseline "$@" > /dev/null 2> "$OUT/write.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o p -- python3 "$REPO/bench.py" --steps $STEPS --warmup $WARM --no-cpu-baseline --no-extras "$@" > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o p -- python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-extras "$@" > /dev/null 2> "$OUT/fetch.err"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -o p -- python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-extras "$@" > /dev/null 2> "$OUT/write.err"
 S=$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)
 T=$(find "$OUT/stats" -name '*kernel_trace.csv' | head -1)
 F=$(find "$OUT/fetch" -name '*counter_collection.csv' | head -1)
