@@ -709,15 +709,36 @@ __global__ __launch_bounds__(256) void exact_select_kernel(const float *__restri
     const int kk = (int)(k < n_items ? k : n_items);
     uint64_t prev = 0;
     bool have_prev = false;
-    for (int r = 0; r < kk; r++) {
-        uint64_t best = ~0ull;
-        for (int64_t i = tid; i < n_items; i += 256) {
-            const uint64_t key = ((uint64_t)f32_orderable(a[i]) << 32) | (uint32_t)i;
-            if ((!have_prev || key > prev) && key < best) best = key;
+    constexpr int HELD = 32;   // a shard of up to 8192 rows: the scan values of the query stay in registers for all k rounds
+    if (n_items <= 256 * HELD) {
+        uint32_t key32[HELD];
+#pragma unroll
+        for (int u = 0; u < HELD; u++) {
+            const int64_t i = tid + 256 * u;
+            key32[u] = i < n_items ? f32_orderable(a[i]) : 0xffffffffu;
         }
-        best = block_min_u64(best, s_red, tid);
-        prev = best;
-        have_prev = true;
+        for (int r = 0; r < kk; r++) {
+            uint64_t best = ~0ull;
+#pragma unroll
+            for (int u = 0; u < HELD; u++) {
+                const uint64_t key = ((uint64_t)key32[u] << 32) | (uint32_t)(tid + 256 * u);
+                if (tid + 256 * u < n_items && (!have_prev || key > prev) && key < best) best = key;
+            }
+            best = block_min_u64(best, s_red, tid);
+            prev = best;
+            have_prev = true;
+        }
+    } else {
+        for (int r = 0; r < kk; r++) {
+            uint64_t best = ~0ull;
+            for (int64_t i = tid; i < n_items; i += 256) {
+                const uint64_t key = ((uint64_t)f32_orderable(a[i]) << 32) | (uint32_t)i;
+                if ((!have_prev || key > prev) && key < best) best = key;
+            }
+            best = block_min_u64(best, s_red, tid);
+            prev = best;
+            have_prev = true;
+        }
     }
     const float thr = f32_from_orderable((uint32_t)(prev >> 32)) + eps;
     if (tid == 0) s_n = 0;
@@ -732,31 +753,53 @@ __global__ __launch_bounds__(256) void exact_select_kernel(const float *__restri
     if (tid == 0) ncand_out[qi] = s_n;   // may exceed cap: the host then retries with more room
 }
 
-// cosine_distance in the reference's order (morna.py:101-114): one thread per candidate
-__global__ __launch_bounds__(256) void exact_rerank_kernel(const float *__restrict__ X, int32_t dim, int32_t dpad,
+// cosine_distance in the reference's order (morna.py:101-114): one thread per candidate walks ITS row front to back in
+// fp64 (pp += i*i; qq += j*j; pq += i*j), a 128-byte line of the row requested ahead of the one being consumed; the query
+// is read through wave-uniform loads.  The pass is bound by the issue of its three dependent fp64 chains (8192 steps each
+// at D = 8192), i.e. by the NUMBER of candidates: what keeps it short is the width of the scan's window (exact_scan_eps).
+// Tried at configs[4]'s shard (6250 queries, ~100 candidates each when the window was 1e-3): rows staged through LDS by the
+// whole workgroup 5.9 ms, a parallel-fp64 narrowing pass in front 4.4 ms, this form 3.4 ms.
+#define RR_COLS 32
+#define RR_THREADS 64   // one wave per query: the candidates are a few dozen, and a wave that waits for its chains leaves the SIMD to other queries
+__global__ __launch_bounds__(RR_THREADS) void exact_rerank_kernel(const float *__restrict__ X, int32_t dim, int32_t dpad,
                                                            const double *__restrict__ Qd /* [nq][dim] */,
                                                            const int32_t *__restrict__ cand, const int32_t *__restrict__ ncand,
                                                            int32_t cap, int32_t k, double *__restrict__ cdist /* [nq][cap] */,
                                                            int32_t *__restrict__ ids_out, double *__restrict__ dist_out,
                                                            int32_t *__restrict__ count_out)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *qs = (double *)smem;   // [dim]
     const int tid = threadIdx.x;
     const int64_t qi = blockIdx.x;
-    for (int i = tid; i < dim; i += 256) qs[i] = Qd[qi * dim + i];
-    __syncthreads();
+    const double *q = Qd + qi * dim;
     const int n = ncand[qi] < cap ? ncand[qi] : cap;
     const int32_t *c = cand + qi * cap;
     double *cd = cdist + qi * cap;
-    for (int t = tid; t < n; t += 256) {
-        const float *row = X + (int64_t)c[t] * dpad;
+    for (int t = tid; t < n; t += RR_THREADS) {
+        const float4 *row = (const float4 *)(X + (int64_t)c[t] * dpad);
         double pp = 0.0, qq = 0.0, pq = 0.0;
-        for (int z = 0; z < dim; z++) {
-            const double i = (double)row[z], j = qs[z];
-            pp = __dadd_rn(pp, __dmul_rn(i, i));
-            qq = __dadd_rn(qq, __dmul_rn(j, j));
-            pq = __dadd_rn(pq, __dmul_rn(i, j));
+        float4 cur[RR_COLS / 4], nxt[RR_COLS / 4];
+#pragma unroll
+        for (int u = 0; u < RR_COLS / 4; u++) cur[u] = row[u];   // (dpad is a multiple of 256: every line read exists)
+        for (int z0 = 0; z0 < dim; z0 += RR_COLS) {
+            const bool more = z0 + RR_COLS < dim;
+#pragma unroll
+            for (int u = 0; u < RR_COLS / 4; u++) nxt[u] = row[(more ? z0 + RR_COLS : z0) / 4 + u];
+            const int zn = dim - z0 < RR_COLS ? dim - z0 : RR_COLS;
+#pragma unroll
+            for (int u = 0; u < RR_COLS / 4; u++) {
+                const float e4[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    if (4 * u + v < zn) {
+                        const double i = (double)e4[v], j = q[z0 + 4 * u + v];
+                        pp = __dadd_rn(pp, __dmul_rn(i, i));
+                        qq = __dadd_rn(qq, __dmul_rn(j, j));
+                        pq = __dadd_rn(pq, __dmul_rn(i, j));
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RR_COLS / 4; u++) cur[u] = nxt[u];
         }
         const double ppqq = __dmul_rn(pp, qq);
         double distance = 2.0;
@@ -772,14 +815,14 @@ __global__ __launch_bounds__(256) void exact_rerank_kernel(const float *__restri
     __syncthreads();
     {
         bool any_nan = false;
-        for (int t = tid; t < n; t += 256) any_nan |= cd[t] != cd[t];
+        for (int t = tid; t < n; t += RR_THREADS) any_nan |= cd[t] != cd[t];
         if (any_nan) s_nan = 1;
     }
     __syncthreads();
     // rank = number of candidates that bisect_left insertion leaves in front:
     // smaller distance, or equal distance and HIGHER id (inserted later, lands first).
     // NaN distances go last, by ascending id (the lists are still filled in, for diagnosis).
-    for (int t = tid; t < n; t += 256) {
+    for (int t = tid; t < n; t += RR_THREADS) {
         const double d = cd[t];
         const int32_t id = c[t];
         const bool dnan = d != d;
@@ -798,7 +841,7 @@ __global__ __launch_bounds__(256) void exact_rerank_kernel(const float *__restri
         }
     }
     const int kout = k < n ? k : n;
-    for (int r = kout + tid; r < k; r += 256) {
+    for (int r = kout + tid; r < k; r += RR_THREADS) {
         ids_out[qi * k + r] = -1;
         dist_out[qi * k + r] = INFINITY;
     }
@@ -832,6 +875,7 @@ __global__ void exact_prep_kernel(const double *__restrict__ Qd, int64_t nq, int
 #define MM_TILE 128
 #define MM_BK 32
 #define MM_LD (MM_BK + 4)   // padded LDS row (floats); 144-byte rows keep float4 accesses aligned
+#define MM_FLUSH 128        // columns per accumulation chain of the scan (a multiple of MM_BK, a power of two)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256, 2) void exact_scan_mfma_kernel(const float *__restrict__ X, const float *__restrict__ norm2,
@@ -864,9 +908,12 @@ __global__ __launch_bounds__(256, 2) void exact_scan_mfma_kernel(const float *__
             *(float4 *)(Bs + row * MM_LD + c4 * 4) = gb[it];
         }
     };
-    // two accumulators per tile, taking the 8-column blocks of a K slab alternately: an accumulation chain is
-    // dpad / 2 products long, which is what exact_scan_eps() prices
-    f32x16 acc[2][2], acc_b[2][2];
+    // Blocked accumulation: the running accumulator of a tile is added into a second one every MM_FLUSH columns and
+    // cleared, so that a chain of fmaf is MM_FLUSH products long and the second level adds dpad / MM_FLUSH partial sums --
+    // an error bound of (MM_FLUSH + dpad / MM_FLUSH) u instead of dpad / 2 u (one chain per half of the columns, as this
+    // kernel first had it): the selection window of exact_scan_eps() is 12x narrower at D = 8192, and the fp64 re-rank,
+    // whose time is the number of candidates, 3-4x shorter.
+    f32x16 acc[2][2], acc_b[2][2];   // running chain; sum of the flushed chains
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -894,11 +941,21 @@ __global__ __launch_bounds__(256, 2) void exact_scan_mfma_kernel(const float *__
             for (int tm = 0; tm < 2; tm++)
 #pragma unroll
                 for (int tn = 0; tn < 2; tn++) {
-                    f32x16 &c = (blk & 1) ? acc_b[tm][tn] : acc[tm][tn];
+                    f32x16 &c = acc[tm][tn];
                     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].x, b4[tn].x, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].y, b4[tn].y, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].z, b4[tn].z, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].w, b4[tn].w, c, 0, 0, 0);
+                }
+        }
+        if (((k0 + MM_BK) & (MM_FLUSH - 1)) == 0 || !more) {   // uniform: the chain ends here
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                for (int tn = 0; tn < 2; tn++) {
+                    acc_b[tm][tn] = acc_b[tm][tn] + acc[tm][tn];
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[tm][tn][e] = 0.f;
                 }
         }
         __syncthreads();
@@ -908,7 +965,7 @@ __global__ __launch_bounds__(256, 2) void exact_scan_mfma_kernel(const float *__
 #pragma unroll
     for (int tm = 0; tm < 2; tm++)
 #pragma unroll
-        for (int tn = 0; tn < 2; tn++) acc[tm][tn] = acc[tm][tn] + acc_b[tm][tn];
+        for (int tn = 0; tn < 2; tn++) acc[tm][tn] = acc_b[tm][tn];
     // epilogue: C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
     // A (queries) indexes the rows of the tile, B (matrix rows) its columns: 32 lanes write 32 consecutive r.
 #pragma unroll
@@ -932,14 +989,15 @@ __global__ __launch_bounds__(256, 2) void exact_scan_mfma_kernel(const float *__
 // threshold and the candidate itself can both be off): every row within this of the threshold is kept, so no row
 // of the true top k is lost.  Unit roundoff u = 2^-24, errors relative to |x| |q| >= sum |x_i q_i|:
 //   dot, vector-ALU scan : a lane adds dpad / 64 products in turn, then the 6-stage butterfly
-//   dot, matrix-core scan: two chains of dpad / 2 products each (one rounding per product-accumulate; measured on
-//                          MI355X by scripts/mfma_accum_probe.hip, profiles/r02_mfma_accum_probe.txt) and their sum
+//   dot, matrix-core scan: chains of MM_FLUSH products (v_mfma_f32_32x32x2_f32 is a chain of IEEE fmaf: measured bit for
+//                          bit on MI355X by scripts/mfma_accum_probe.hip, profiles/r02_mfma_accum_probe.txt), their
+//                          dpad / MM_FLUSH partial sums added one after the other
 //   norms (norm2 of the row, qn2 of the query): sums of dpad / 64 squares per lane + butterfly; half of each enters cos
 //   the fp32 image of the query and the rounding of the value itself: 2 u
 static float exact_scan_eps(int32_t dpad, bool mfma)
 {
     const double u = 5.9604644775390625e-8;
-    const double e_dot = mfma ? (dpad / 2 + 8) * u : (dpad / 64 + 8) * u;
+    const double e_dot = mfma ? (MM_FLUSH + dpad / MM_FLUSH + 8) * u : (dpad / 64 + 8) * u;
     const double e_norm = (dpad / 64 + 8) * u;
     return (float)(2.0 * 2.0 * (e_dot + e_norm + 2 * u));
 }
@@ -1010,6 +1068,7 @@ int exact_search(morna_index *h, const double *q, int64_t nq, int32_t k, int32_t
         }
         HIP_TRY(hipGetLastError());
         const float eps = exact_scan_eps(dpad, nb >= 32);   // which scan ran
+        ScopedTimer tm_sel(h, MORNA_T_EXACT, 0);            // selection + fp64 re-rank: the same group as the scan
         for (;;) {
             MORNA_TRY(cand.alloc((size_t)batch * cap));
             MORNA_TRY(cdist.alloc((size_t)batch * cap));
@@ -1023,7 +1082,7 @@ int exact_search(morna_index *h, const double *q, int64_t nq, int32_t k, int32_t
             if (need <= cap) break;
             cap = need;   // huge tie groups at the boundary: make room for all of them
         }
-        hipLaunchKernelGGL(exact_rerank_kernel, dim3((unsigned)nb), dim3(256), (size_t)D * 8, h->stream, h->X.p, D, dpad,
+        hipLaunchKernelGGL(exact_rerank_kernel, dim3((unsigned)nb), dim3(RR_THREADS), 0, h->stream, h->X.p, D, dpad,
                            Qd.p, cand.p, ncand.p, cap, k, cdist.p, d_ids.p, d_dist.p, d_cnt.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(ids_out + q0 * k, d_ids.p, (size_t)nb * k * 4, hipMemcpyDeviceToHost, h->stream));
