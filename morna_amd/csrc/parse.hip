@@ -9,11 +9,18 @@
 // section 8f N1); this does the same work at I/O speed.
 #include <zlib.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -134,6 +141,221 @@ int morna_lines_free(morna_lines *L)
     return MORNA_OK;
 }
 
+// ---- the pipeline ---------------------------------------------------------------------------------------------
+// One thread inflates the file into blocks cut at line ends; worker threads tokenise the blocks (the per-character work:
+// tabs, commas, decimal numbers); the calling thread merges the blocks IN FILE ORDER, which is where everything that is
+// sequential by definition happens -- the threshold, the cumulative frequency of a key and its idf, first-seen internal
+// ids (morna.py:357-382).  gzip inflation cannot be spread over threads, so it is the floor of the wall-clock; the
+// single-threaded pass it replaces spent as long again on the tokenising.  MORNA_PARSE_THREADS sets the workers (default:
+// the cores available, at most 12; 1: everything on the calling thread, no thread is started).
+
+struct ParsedLine {
+    int32_t err;                 // 0 ok, 1 fewer than two columns, 2 invalid literal for int()
+    uint32_t key_off, key_len;   // into ParsedBlock::keys
+    int64_t first;               // into ParsedBlock::samples / covs
+    int32_t n_samples, n_covs;
+};
+struct ParsedBlock {
+    std::string text;            // the block's lines (whole lines only)
+    int64_t first_line = 0;      // number of the block's first line, from 1
+    std::vector<ParsedLine> lines;
+    std::string keys;
+    std::vector<int64_t> samples, covs;   // per line: n_samples values in samples[first ..], n_covs in covs[first2 ..]
+    std::vector<int64_t> cov_first;       // start of each line's coverages in covs
+    std::vector<std::string> ids_seen;    // count_samples mode: the sample-id strings of column -2
+    std::atomic<bool> done{false};
+};
+
+// tokenise one block (what go_index does to each line before add_junction: morna.py:848-853)
+static void parse_block(ParsedBlock &B, bool count_only)
+{
+    const std::string &s = B.text;
+    std::vector<std::pair<size_t, size_t>> tok;
+    size_t pos = 0;
+    while (pos < s.size()) {
+        size_t nl = s.find('\n', pos);
+        const size_t end_line = nl == std::string::npos ? s.size() : nl;
+        ParsedLine L;
+        L.err = 0;
+        L.key_off = (uint32_t)B.keys.size();
+        L.key_len = 0;
+        L.first = (int64_t)B.samples.size();
+        L.n_samples = L.n_covs = 0;
+        if (count_only) {
+            // the reference splits the raw line here (no strip): column -2 can never hold the newline
+            split_tabs(s, pos, end_line, tok);
+            if (tok.size() < 2) {
+                L.err = 1;
+            } else {
+                const auto &t = tok[tok.size() - 2];
+                size_t st = t.first;
+                for (size_t i = t.first; i <= t.second; i++)
+                    if (i == t.second || s[i] == ',') {
+                        B.ids_seen.emplace_back(s.data() + st, i - st);
+                        st = i + 1;
+                    }
+            }
+            B.lines.push_back(L);
+            B.cov_first.push_back(0);
+            pos = end_line + 1;
+            continue;
+        }
+        size_t b = pos, e = end_line;   // tokens = line.strip().split('\t')
+        while (b < e && is_space(s[b])) b++;
+        while (e > b && is_space(s[e - 1])) e--;
+        split_tabs(s, b, e, tok);
+        B.cov_first.push_back((int64_t)B.covs.size());
+        if (tok.size() < 2) {
+            L.err = 1;
+        } else {
+            for (size_t i = 0; i < tok.size() && i < 3; i++) {   // ' '.join(tokens[:3])
+                if (i) B.keys.push_back(' ');
+                B.keys.append(s, tok[i].first, tok[i].second - tok[i].first);
+            }
+            L.key_len = (uint32_t)(B.keys.size() - L.key_off);
+            auto parse_list = [&](const std::pair<size_t, size_t> &t, std::vector<int64_t> &dst, int32_t &n) {
+                size_t st = t.first;
+                for (size_t i = t.first; i <= t.second; i++)
+                    if (i == t.second || s[i] == ',') {
+                        int64_t v;
+                        if (!parse_int(s.data() + st, s.data() + i, v)) return false;
+                        dst.push_back(v);
+                        n++;
+                        st = i + 1;
+                    }
+                return true;
+            };
+            if (!parse_list(tok[tok.size() - 2], B.samples, L.n_samples) || !parse_list(tok[tok.size() - 1], B.covs, L.n_covs)) L.err = 2;
+        }
+        B.lines.push_back(L);
+        pos = end_line + 1;
+    }
+    B.done = true;
+}
+
+// the reader + workers; next_block() hands the blocks over in file order
+struct BlockPipeline {
+    static constexpr size_t BLOCK_BYTES = (size_t)4 << 20;
+    gzFile f = nullptr;
+    bool count_only = false;
+    int n_workers = 1;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done, cv_room;
+    std::deque<std::unique_ptr<ParsedBlock>> blocks;   // in file order; front = next to merge
+    size_t next_to_parse = 0;                          // index into blocks of the first block no worker has taken
+    bool eof = false;
+    std::vector<std::thread> threads;
+    size_t max_in_flight = 32;
+
+    bool read_block(std::string &carry, ParsedBlock &B, int64_t &line_no)
+    {
+        // whole lines only: what follows the last newline is carried into the next block
+        std::string &t = B.text;
+        t.swap(carry);
+        carry.clear();
+        B.first_line = line_no;
+        for (;;) {
+            const size_t old = t.size();
+            t.resize(old + BLOCK_BYTES);
+            const int got = gzread(f, &t[old], (unsigned)BLOCK_BYTES);
+            t.resize(old + (got > 0 ? (size_t)got : 0));
+            if (got <= 0) break;                                    // end of file (or a read error: what was read is used)
+            const size_t nl = t.rfind('\n');
+            if (nl != std::string::npos) {
+                carry.assign(t, nl + 1, std::string::npos);
+                t.resize(nl + 1);
+                break;
+            }
+        }
+        if (t.empty()) return false;
+        for (char ch : t) line_no += ch == '\n';
+        if (t.back() != '\n') line_no++;                            // the file's last line without a terminator
+        return true;
+    }
+
+    void start(const char *path_unused, bool count, int workers)
+    {
+        (void)path_unused;
+        count_only = count;
+        n_workers = workers;
+        if (n_workers <= 1) return;
+        threads.emplace_back([this] {   // the reader: inflation
+            std::string carry;
+            int64_t line_no = 1;
+            for (;;) {
+                std::unique_ptr<ParsedBlock> B(new ParsedBlock());
+                const bool any = read_block(carry, *B, line_no);
+                std::unique_lock<std::mutex> lk(mu);
+                if (!any) {
+                    eof = true;
+                    cv_work.notify_all();
+                    cv_done.notify_all();
+                    return;
+                }
+                cv_room.wait(lk, [this] { return blocks.size() < max_in_flight; });
+                blocks.push_back(std::move(B));
+                cv_work.notify_one();
+            }
+        });
+        for (int w = 0; w < n_workers - 1; w++)
+            threads.emplace_back([this] {   // the tokenisers
+                for (;;) {
+                    ParsedBlock *B = nullptr;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv_work.wait(lk, [this] { return next_to_parse < blocks.size() || eof; });
+                        if (next_to_parse >= blocks.size()) return;   // eof and nothing left
+                        B = blocks[next_to_parse++].get();
+                    }
+                    parse_block(*B, count_only);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        cv_done.notify_all();
+                    }
+                }
+            });
+    }
+
+    std::string carry1;
+    int64_t line1 = 1;
+    // the next block in file order, tokenised; null at the end of the file
+    std::unique_ptr<ParsedBlock> next_block()
+    {
+        if (n_workers <= 1) {
+            std::unique_ptr<ParsedBlock> B(new ParsedBlock());
+            if (!read_block(carry1, *B, line1)) return nullptr;
+            parse_block(*B, count_only);
+            return B;
+        }
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [this] { return (!blocks.empty() && blocks.front()->done) || (eof && blocks.empty()); });
+        if (blocks.empty()) return nullptr;
+        std::unique_ptr<ParsedBlock> B = std::move(blocks.front());
+        blocks.pop_front();
+        next_to_parse--;   // indices shift with the pop; the front block was taken by a worker long ago
+        cv_room.notify_one();
+        return B;
+    }
+
+    void stop()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            max_in_flight = (size_t)-1;   // let the reader run to the end if the caller bailed out early
+            cv_room.notify_all();
+        }
+        for (std::thread &t : threads) t.join();
+        threads.clear();
+    }
+};
+
+static int parse_threads()
+{
+    if (const char *e = getenv("MORNA_PARSE_THREADS")) return std::max(1, atoi(e));
+    const unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::min<unsigned>(std::max<unsigned>(hc, 1u), 12u);
+}
+
 int morna_parse_intropolis(const char *path, int64_t sample_count, int64_t sample_threshold, morna_lines **out)
 {
     if (!path || !out) {
@@ -141,110 +363,124 @@ int morna_parse_intropolis(const char *path, int64_t sample_count, int64_t sampl
         return MORNA_E_INVALID;
     }
     *out = nullptr;
-    std::string line;
-    std::vector<std::pair<size_t, size_t>> tok;
+    const int workers = parse_threads();
     if (sample_count <= 0) {
         // count_samples (morna.py:789-822): distinct sample-id STRINGS of column -2
-        LineReader r;
-        if (!r.open(path)) {
+        BlockPipeline P;
+        P.f = gzopen(path, "rb");   // transparently reads plain text too
+        if (!P.f) {
             set_error("Unable to open %s", path);
             return MORNA_E_IO;
         }
+        gzbuffer(P.f, 1 << 20);
+        P.start(path, true, workers);
         std::unordered_set<std::string> seen;
-        while (r.next(line)) {
-            // the reference splits the raw line here (no strip): column -2 can never hold the newline
-            size_t e = line.size();
-            split_tabs(line, 0, e, tok);
-            if (tok.size() < 2) {
-                set_error("line %lld of %s has fewer than two tab-separated columns", (long long)seen.size(), path);
-                return MORNA_E_INVALID;
-            }
-            const auto &t = tok[tok.size() - 2];
-            size_t s = t.first;
-            for (size_t i = t.first; i <= t.second; i++)
-                if (i == t.second || line[i] == ',') {
-                    seen.emplace(line.data() + s, i - s);
-                    s = i + 1;
+        int rc = MORNA_OK;
+        while (std::unique_ptr<ParsedBlock> B = P.next_block()) {
+            if (rc != MORNA_OK) continue;   // drain
+            for (size_t i = 0; i < B->lines.size(); i++)
+                if (B->lines[i].err) {
+                    set_error("line %lld of %s has fewer than two tab-separated columns", (long long)(B->first_line + (int64_t)i), path);
+                    rc = MORNA_E_INVALID;
+                    break;
                 }
+            if (rc == MORNA_OK)
+                for (std::string &id : B->ids_seen) seen.insert(std::move(id));
         }
+        P.stop();
+        gzclose(P.f);
+        if (rc != MORNA_OK) return rc;
         sample_count = (int64_t)seen.size();
     }
-    LineReader r;
-    if (!r.open(path)) {
+    BlockPipeline P;
+    P.f = gzopen(path, "rb");
+    if (!P.f) {
         set_error("Unable to open %s", path);
         return MORNA_E_IO;
     }
+    gzbuffer(P.f, 1 << 20);
+    P.start(path, false, workers);
     morna_lines *L = new morna_lines();
     L->sample_count = sample_count;
-    std::unordered_map<int64_t, int32_t> id_map;   // internal_id_map (morna.py:377-382)
-    std::vector<int64_t> samples, covs;
+    // internal_id_map (morna.py:377-382): a table indexed by the sample id while the ids are small non-negative numbers
+    // (1e8 look-ups are the merge's cost), a hash map for the others
+    std::vector<int32_t> dense;
+    std::unordered_map<int64_t, int32_t> sparse;
+    constexpr int64_t DENSE_MAX = (int64_t)1 << 26;
     std::string key;
+    int rc = MORNA_OK;
     int64_t lineno = 0;
-    while (r.next(line)) {
-        lineno++;
-        size_t b, e;
-        strip(line, b, e);                                   // tokens = line.strip().split('\t')
-        split_tabs(line, b, e, tok);
-        if (tok.size() < 2) {
-            set_error("line %lld of %s has fewer than two tab-separated columns", (long long)lineno, path);
-            delete L;
-            return MORNA_E_INVALID;
-        }
-        key.clear();                                         // ' '.join(tokens[:3])
-        for (size_t i = 0; i < tok.size() && i < 3; i++) {
-            if (i) key.push_back(' ');
-            key.append(line, tok[i].first, tok[i].second - tok[i].first);
-        }
-        auto parse_list = [&](const std::pair<size_t, size_t> &t, std::vector<int64_t> &dst) {
-            dst.clear();
-            size_t s = t.first;
-            for (size_t i = t.first; i <= t.second; i++)
-                if (i == t.second || line[i] == ',') {
-                    int64_t v;
-                    if (!parse_int(line.data() + s, line.data() + i, v)) return false;
-                    dst.push_back(v);
-                    s = i + 1;
+    while (std::unique_ptr<ParsedBlock> B = P.next_block()) {
+        if (rc != MORNA_OK) continue;   // an error further up the file: drain the pipeline
+        for (size_t li = 0; li < B->lines.size() && rc == MORNA_OK; li++) {
+            const ParsedLine &PL = B->lines[li];
+            lineno = B->first_line + (int64_t)li;
+            if (PL.err == 1) {
+                set_error("line %lld of %s has fewer than two tab-separated columns", (long long)lineno, path);
+                rc = MORNA_E_INVALID;
+                break;
+            }
+            if (PL.err == 2) {
+                set_error("invalid literal for int() on line %lld of %s", (long long)lineno, path);
+                rc = MORNA_E_INVALID;
+                break;
+            }
+            if ((int64_t)PL.n_samples < sample_threshold) {    // morna.py:361-363
+                L->skipped++;
+                continue;
+            }
+            key.assign(B->keys, PL.key_off, PL.key_len);
+            auto it = L->freq.find(key);
+            if (it == L->freq.end()) {
+                it = L->freq.emplace(key, 0).first;
+                L->freq_keys.push_back(key);
+            }
+            it->second += (int64_t)PL.n_samples;               // morna.py:365
+            L->idf.push_back(log((double)sample_count / (double)it->second));   // morna.py:372-374
+            L->key_bytes.insert(L->key_bytes.end(), key.begin(), key.end());
+            L->key_off.push_back((int64_t)L->key_bytes.size());
+            const int32_t n = PL.n_samples < PL.n_covs ? PL.n_samples : PL.n_covs;   // zip() truncates
+            const int64_t *sm = B->samples.data() + PL.first, *cv = B->covs.data() + B->cov_first[li];
+            const size_t at = L->item_ids.size();
+            L->item_ids.resize(at + (size_t)n);
+            L->cov.resize(at + (size_t)n);
+            for (int32_t i = 0; i < n; i++) {
+                const int64_t sid = sm[i];
+                int32_t id;
+                if (sid >= 0 && sid < DENSE_MAX) {
+                    if ((size_t)sid >= dense.size()) dense.resize((size_t)std::max<int64_t>(sid + 1, (int64_t)dense.size() * 2), -1);
+                    id = dense[(size_t)sid];
+                    if (id < 0) {
+                        id = dense[(size_t)sid] = (int32_t)L->ext_ids.size();
+                        L->ext_ids.push_back(sid);
+                    }
+                } else {
+                    auto f = sparse.find(sid);
+                    if (f == sparse.end()) {
+                        id = (int32_t)L->ext_ids.size();
+                        sparse.emplace(sid, id);
+                        L->ext_ids.push_back(sid);
+                    } else {
+                        id = f->second;
+                    }
                 }
-            return true;
-        };
-        if (!parse_list(tok[tok.size() - 2], samples) || !parse_list(tok[tok.size() - 1], covs)) {
-            set_error("invalid literal for int() on line %lld of %s", (long long)lineno, path);
-            delete L;
-            return MORNA_E_INVALID;
-        }
-        if ((int64_t)samples.size() < sample_threshold) {    // morna.py:361-363
-            L->skipped++;
-            continue;
-        }
-        auto it = L->freq.find(key);
-        if (it == L->freq.end()) {
-            it = L->freq.emplace(key, 0).first;
-            L->freq_keys.push_back(key);
-        }
-        it->second += (int64_t)samples.size();               // morna.py:365
-        L->idf.push_back(log((double)sample_count / (double)it->second));   // morna.py:372-374
-        L->key_bytes.insert(L->key_bytes.end(), key.begin(), key.end());
-        L->key_off.push_back((int64_t)L->key_bytes.size());
-        const size_t n = samples.size() < covs.size() ? samples.size() : covs.size();   // zip() truncates
-        for (size_t i = 0; i < n; i++) {
-            auto f = id_map.find(samples[i]);
-            int32_t id;
-            if (f == id_map.end()) {
-                id = (int32_t)L->ext_ids.size();
-                id_map.emplace(samples[i], id);
-                L->ext_ids.push_back(samples[i]);
-            } else {
-                id = f->second;
+                if (cv[i] > INT32_MAX || cv[i] < INT32_MIN) {   // the staged arrays are int32; the reference keeps Python ints
+                    set_error("coverage %lld on line %lld of %s does not fit 32 bits", (long long)cv[i], (long long)lineno, path);
+                    rc = MORNA_E_INVALID;
+                    break;
+                }
+                L->item_ids[at + (size_t)i] = id;
+                L->cov[at + (size_t)i] = (int32_t)cv[i];
             }
-            if (covs[i] > INT32_MAX || covs[i] < INT32_MIN) {   // the staged arrays are int32; the reference keeps Python ints
-                set_error("coverage %lld on line %lld of %s does not fit 32 bits", (long long)covs[i], (long long)lineno, path);
-                delete L;
-                return MORNA_E_INVALID;
-            }
-            L->item_ids.push_back(id);
-            L->cov.push_back((int32_t)covs[i]);
+            if (rc == MORNA_OK) L->row_ptr.push_back((int64_t)L->item_ids.size());
         }
-        L->row_ptr.push_back((int64_t)L->item_ids.size());
+        if (rc == MORNA_OK) lineno = B->first_line + (int64_t)B->lines.size() - 1;
+    }
+    P.stop();
+    gzclose(P.f);
+    if (rc != MORNA_OK) {
+        delete L;
+        return rc;
     }
     L->lines_read = lineno;
     L->freq_vals.reserve(L->freq_keys.size());

@@ -290,3 +290,47 @@ def test_write_intropolis_round_trip(tmp_path, gz):
     for k in ("key_bytes", "key_off", "row_ptr", "ids", "cov", "ext_ids"):
         assert a[k].tolist() == np.asarray(want[k]).tolist(), k
     assert a["idf"].tobytes() == want["idf"].tobytes()
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_native_parser_pipeline_equals_single_thread(tmp_path, monkeypatch, gz):
+    """The reader / tokeniser / ordered-merge pipeline (MORNA_PARSE_THREADS > 1) gives exactly the arrays of the
+    one-thread pass: blocks of 4 MB cut at line ends, lines far longer than a block, a last line without a terminator,
+    duplicate keys (cumulative frequency), skipped lines, zip() truncation, counted sample_count -- and reports the
+    FIRST bad line of the file, as the sequential pass does."""
+    rng = np.random.default_rng(21)
+    lines = []
+    for j in range(900):
+        n = 650_000 if j in (5, 401, 899) else int(rng.integers(1, 300))   # three lines of ~4.5 MB: longer than a block
+        ids = np.sort(rng.choice(1_000_000, size=n, replace=False))
+        cov = rng.integers(1, 300, size=n - (1 if j % 50 == 7 else 0))    # some lines: one coverage short
+        key = "chr%d\t%d\t%d" % (j % 22 + 1, 1000 + (j % 300), 5000 + (j % 300))   # keys repeat
+        lines.append("%s\t+\tGT\tAG\t%s\t%s\n" % (key, ",".join(map(str, ids.tolist())), ",".join(map(str, cov.tolist()))))
+    lines[-1] = lines[-1].rstrip("\n")
+    p = str(tmp_path / ("p.tsv.gz" if gz else "p.tsv"))
+    _write(p, lines, gz)
+
+    def run(threads, sample_count):
+        monkeypatch.setenv("MORNA_PARSE_THREADS", str(threads))
+        got = mindex.ParsedLines(p, sample_count, 50)
+        a = got.arrays()
+        return ([got.n_lines, got.nnz, got.n_items, got.skipped, got.sample_count, got.lines_read],
+                {k: a[k].tobytes() for k in a}, got.frequencies())
+    one = run(1, None)
+    assert one[0][5] == 900 and one[0][3] > 0
+    for threads in (2, 5):
+        many = run(threads, None)
+        assert many[0] == one[0] and many[2] == one[2]
+        for k in one[1]:
+            assert many[1][k] == one[1][k], k
+    # the first bad line wins, whichever block a worker finishes first
+    bad = list(lines)
+    bad[-1] += "\n"
+    bad[400] = bad[400].replace(",", ",x", 1)     # (line 401 of the file)
+    bad[700] = "justonecolumn\n"
+    pb = str(tmp_path / ("b.tsv.gz" if gz else "b.tsv"))
+    _write(pb, bad, gz)
+    for threads in (1, 4):
+        monkeypatch.setenv("MORNA_PARSE_THREADS", str(threads))
+        with pytest.raises(ValueError, match="line 401 "):
+            mindex.ParsedLines(pb, 5, 1)
