@@ -131,7 +131,8 @@ int morna_index_create(int32_t dim, int32_t device, morna_index **out)
         rc = MORNA_E_HIP;
     }
     if (rc != MORNA_OK) {
-        if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+        if (h->ev_tables) (void)hipEventDestroy(h->ev_tables);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
         if (h->ev_join) (void)hipEventDestroy(h->ev_join);
         if (h->stream2) (void)hipStreamDestroy(h->stream2);
         (void)hipStreamDestroy(h->stream);
@@ -153,6 +154,7 @@ int morna_index_destroy(morna_index *h)
     }
     for (hipEvent_t e : h->free_ev) (void)hipEventDestroy(e);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    if (h->ev_tables) (void)hipEventDestroy(h->ev_tables);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->host_counts) (void)hipHostFree(h->host_counts);
@@ -422,6 +424,7 @@ int morna_get_forest(morna_index *h, int32_t *node_rec, int32_t *perm, float *hy
         return MORNA_E_STATE;
     }
     HIP_TRY(hipSetDevice(h->device));
+    MORNA_TRY(settle(h));
     const int64_t n = h->n_nodes;
     if (node_rec)
         for (int64_t i = 0; i < n; i++) {

@@ -121,6 +121,8 @@ struct morna_index {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;                 // side stream of the forest build (work that does not depend on two_means)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_tables = nullptr;    // behind the node-table copies of the last forest build
+    bool ev_tables_pending = false;
     // right-side counts of a level, written by partition_kernel straight into page-locked host memory ((epoch << 32) |
     // count per task): the host polls them instead of an event hand-over + copy + stream wait per level
     unsigned long long *host_counts = nullptr;

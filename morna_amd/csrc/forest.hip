@@ -949,6 +949,10 @@ __global__ void iota_perm_kernel(int32_t *perm, int32_t *inv, int64_t n_items, i
 
 int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
 {
+    if (h->ev_tables_pending) {   // a previous build may still be copying the host node tables this one is about to clear
+        HIP_TRY(hipEventSynchronize(h->ev_tables));   // (only those copies: what was enqueued since is not waited for)
+        h->ev_tables_pending = false;
+    }
     MORNA_TRY(upload_host_rows(h));
     if (h->n_items <= 0) {
         set_error("no items were added to the index before build()");
@@ -1344,8 +1348,13 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
     F_TRY(hipMemcpyAsync(h->node_rec.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice, h->stream));
     F_TRY(hipMemcpyAsync(h->node_tree.p, ntree.data(), ntree.size() * 4, hipMemcpyHostToDevice, h->stream));
     F_TRY(hipMemcpyAsync(h->node_hp.p, nhp.data(), nhp.size() * 4, hipMemcpyHostToDevice, h->stream));
-    F_TRY(hipStreamSynchronize(h->stream));
-    cleanup();
+    // No wait here: the last partition and these copies are ordered on the handle's stream in front of whatever the caller
+    // does next with the handle (a search starts without the device draining first); the host tables they read belong to the
+    // handle and are next touched by another build, which settles first.  Blocking copies settle() as well.
+    if (!h->ev_tables) F_TRY(hipEventCreateWithFlags(&h->ev_tables, hipEventDisableTiming));
+    F_TRY(hipEventRecord(h->ev_tables, h->stream));
+    h->ev_tables_pending = true;
+    h->unsettled = true;
 #undef F_TRY
     h->stats.n_nodes = h->n_nodes;
     h->stats.n_split = h->n_split;
