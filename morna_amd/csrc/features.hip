@@ -557,6 +557,123 @@ __global__ __launch_bounds__(256) void transpose_convert_kernel(const float *__r
     }
 }
 
+// ------------------------------- fp32 [D][N] -> fp32 [N][dpad] AND the rows' canonical norms, in one pass
+//
+// One workgroup = 64 positions of the column image, ALL column tiles in ascending order: the cells pass through the LDS
+// tile on their way to the rows (as above), and on the way each thread squares what it holds into the chains of the
+// canonical dot(x, x) -- lane l, component c of wave_dot owns elements 256 k + 4 l + c, one fmaf chain over k: column
+// tile j covers k = j / 4 and lanes 16 (j % 4) .. +15, and thread (tx, ty) reads cells of ONE component c = ty % 4 of row
+// n0 + tx, so it keeps 32 chains (4 quarters x 8 lanes) that receive their terms in ascending k as j ascends.  At the end
+// the four components of a lane meet in LDS, are folded (a0 + a1) + (a2 + a3), and the 64 lane values are added in the butterfly's
+// order (32, 16, 8, 4, 2, 1): bit for bit what row_norms_kernel computes from the finished row, without reading the
+// 0.6 GB of rows again.
+#define TN_TY 4   // waves per workgroup: thread (tx, ty) handles tile rows ty, ty + 4, ... (16 per tile, 64 chains); 8 waves of 8 cells: 1.38 ms against 1.28 for the feature group at C3
+__global__ __launch_bounds__(TT * TN_TY) void transpose_norms_kernel(const float *__restrict__ colacc, int64_t n_items, int32_t dim,
+                                                                     int32_t dpad, const int32_t *__restrict__ item_of,
+                                                                     float *__restrict__ X, float *__restrict__ norm2,
+                                                                     RowInfo *__restrict__ info)
+{
+    constexpr int NI = TT / TN_TY;        // cells of a tile per thread
+    __shared__ float tile[TT][TT + 1];
+    __shared__ float s_ch[4][TT][17];     // one quarter's chains: [component][row][lane of the quarter]
+    __shared__ float s_f[TT][TT + 1];     // folded lane values of every row
+    __shared__ float s_mn[TN_TY][TT];
+    __shared__ int32_t s_item[TT];
+    const int64_t n0 = (int64_t)blockIdx.x * TT;
+    const int tx = threadIdx.x & (TT - 1);
+    const int ty = __builtin_amdgcn_readfirstlane(threadIdx.x / TT);   // a wave = one ty (the column addresses below are scalar)
+    if (threadIdx.x < TT) {
+        const int64_t n = n0 + threadIdx.x;
+        s_item[threadIdx.x] = n < n_items ? (item_of ? item_of[n] : (int32_t)n) : 0;
+    }
+    // tile row r = ty + TN_TY i is column 64 j + r: component c = r % 4 = ty % 4 (the same for all of the thread's cells),
+    // lane 16 (j % 4) + r / 4 = 16 (j % 4) + (ty >> 2) + (TN_TY / 4) i
+    float ch[4][NI];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int i = 0; i < NI; i++) ch[q][i] = 0.f;
+    float mn = INFINITY;   // smallest non-zero |x| this thread has seen
+    const int64_t n = n0 + tx;
+    const int n_tiles = dpad / TT;
+    const uint32_t n_off = (uint32_t)(n < n_items ? n : n_items - 1);   // (a position past the end re-reads the last one; nothing of it is stored)
+    float cur[NI], nxt[NI];
+    auto fetch = [&](int j, float(&v)[NI]) {
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const int32_t c = j * TT + ty + TN_TY * i;                  // uniform over the wave
+            const float *colp = colacc + (int64_t)(c < dim ? c : 0) * n_items;
+            const float x = colp[n_off];
+            v[i] = c < dim ? x : 0.f;
+        }
+    };
+    fetch(0, cur);
+    for (int j0 = 0; j0 < n_tiles; j0 += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {   // dpad is a multiple of 256: four tiles per k
+            const int j = j0 + q;
+            if (j + 1 < n_tiles) fetch(j + 1, nxt);
+            else {
+#pragma unroll
+                for (int i = 0; i < NI; i++) nxt[i] = 0.f;
+            }
+            __syncthreads();   // the previous tile has been written out
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                tile[ty + TN_TY * i][tx] = cur[i];
+                ch[q][i] = fmaf(cur[i], cur[i], ch[q][i]);
+                mn = fminf(mn, cur[i] != 0.f ? fabsf(cur[i]) : INFINITY);
+            }
+            __syncthreads();
+            const int32_t c0 = j * TT;
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                const int r = ty + TN_TY * i;   // uniform over the wave: the row's base address is scalar
+                float *rowp = X + (int64_t)__builtin_amdgcn_readfirstlane(s_item[r]) * dpad + c0;
+                if (n0 + r < n_items) rowp[tx] = tile[tx][r];
+            }
+#pragma unroll
+            for (int i = 0; i < NI; i++) cur[i] = nxt[i];
+        }
+    }
+    // fold: lane l of row tx = (c0 + c1) + (c2 + c3); component c of the quarter's 16 lanes sits in the threads with ty % 4 = c
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NI; i++) s_ch[ty & 3][tx][(ty >> 2) + (TN_TY / 4) * i] = ch[q][i];   // lane of the quarter = tile row / 4
+        __syncthreads();
+        // thread (tx, ty) folds 16 / TN_TY lanes of this quarter
+#pragma unroll
+        for (int u = 0; u < 16 / TN_TY; u++) {
+            const int i = (16 / TN_TY) * ty + u;
+            s_f[tx][16 * q + i] = (s_ch[0][tx][i] + s_ch[1][tx][i]) + (s_ch[2][tx][i] + s_ch[3][tx][i]);
+        }
+    }
+    s_mn[ty][tx] = mn;
+    __syncthreads();
+    if (ty == 0 && n < n_items) {
+        // the butterfly as lane 0 sees it: at stage s lane l < s adds lane l + s (in place, in the row's own LDS line)
+#pragma unroll 1
+        for (int st = 32; st >= 1; st >>= 1)
+#pragma unroll 1
+            for (int l = 0; l < st; l++) s_f[tx][l] = s_f[tx][l] + s_f[tx][l + st];
+        const float d = s_f[tx][0];
+        float m = s_mn[0][tx];
+#pragma unroll
+        for (int y = 1; y < TN_TY; y++) m = fminf(m, s_mn[y][tx]);
+        const int32_t item = s_item[tx];
+        norm2[item] = d;
+        const float norm = sqrtf(d);
+        const bool sub = (double)m < (double)norm * 0x1p-125;   // as row_norms_kernel
+        RowInfo ri;
+        ri.norm2 = d;
+        ri.norm = sub ? -norm : norm;
+        ri.rnorm = 1.0 / (double)norm;
+        info[item] = ri;
+    }
+}
+
 // ------------------------------------------------------------------ row norms
 
 __global__ __launch_bounds__(256) void row_norms_kernel(const float *__restrict__ X, int64_t n_items,
@@ -784,16 +901,31 @@ int build_features(morna_index *h, int64_t n_items)
                                (int32_t)tiles, (int32_t)D, col_off.p, col_lines.p, sidf.p, flags.p, h->s_row_ptr.p, h->s_ids.p,
                                h->s_cov.p, n_items, colacc.p);
         }
-        dim3 tg((unsigned)((n_items + TT - 1) / TT), (unsigned)((h->dpad + TT - 1) / TT));
-        hipLaunchKernelGGL(transpose_convert_kernel, tg, dim3(256), 0, h->stream, colacc.p, n_items, D, h->dpad,
-                           by_order ? (const int32_t *)h->item_at.p : (const int32_t *)nullptr, h->X.p);
+        // the column image becomes the rows, and the rows' canonical norms come out of the same pass (MORNA_FUSED_NORMS=0:
+        // transpose, then row_norms_kernel over the finished rows)
+        static const bool fused = !(getenv("MORNA_FUSED_NORMS") && atoi(getenv("MORNA_FUSED_NORMS")) == 0);
+        const int32_t *item_of = by_order ? (const int32_t *)h->item_at.p : (const int32_t *)nullptr;
+        if (fused) {
+            MORNA_TRY(h->norm2.alloc((size_t)n_items));
+            MORNA_TRY(h->rowinfo.alloc((size_t)n_items));
+            hipLaunchKernelGGL(transpose_norms_kernel, dim3((unsigned)((n_items + TT - 1) / TT)), dim3(TT * TN_TY), 0, h->stream, colacc.p,
+                               n_items, D, h->dpad, item_of, h->X.p, h->norm2.p, h->rowinfo.p);
+        } else {
+            dim3 tg((unsigned)((n_items + TT - 1) / TT), (unsigned)((h->dpad + TT - 1) / TT));
+            hipLaunchKernelGGL(transpose_convert_kernel, tg, dim3(256), 0, h->stream, colacc.p, n_items, D, h->dpad, item_of, h->X.p);
+        }
         HIP_TRY(hipGetLastError());
         h->n_items = n_items;
         h->host_n = 0;
         h->host_rows.clear();
         h->host_dirty = false;
         h->built = false;
-        MORNA_TRY(compute_norms(h));
+        if (fused) {
+            h->norms_valid = true;
+            h->half_valid = false;   // the rows changed: their fp16 image (splitmm.hip) is made again when next needed
+        } else {
+            MORNA_TRY(compute_norms(h));
+        }
     }
     // No synchronisation here: everything above is ordered on the handle's stream and reads no caller memory, and
     // whatever the caller does next with the handle (build, queries, get_items) is ordered behind it or synchronises

@@ -480,3 +480,18 @@ def test_load_rejects_damaged_files(tmp_path):
     b = AnnoyIndex(12)
     b.load(path)                                          # and the intact file still loads
     assert b.get_nns_by_item(5, 4, -1) == a.get_nns_by_item(5, 4, -1)
+
+
+@pytest.mark.parametrize("D,order", [(3000, "ext"), (257, None), (40, "reversed")])
+def test_feature_build_norms_are_canonical(capi, D, order):
+    """The rows' squared norms that come out of the feature build (transpose_norms_kernel: the chains of the canonical dot
+    filled while the column image is turned into rows) are wave_dot(x, x) bit for bit -- what row_norms_kernel computes
+    from finished rows and the oracle's mode-1 dot."""
+    rng = np.random.default_rng(77 + D)
+    keys, rp, s, c = _synthetic_lines(rng, 900, 700, 5, 200)
+    a, prep = _gpu_features(keys, rp, s, c, 900, 20, D, order)
+    X = a.get_items()
+    n2 = a.get_norms2()
+    want = np.array([capi.dot(1, x, x) for x in X], np.float32)
+    assert n2.tobytes() == want.tobytes()
+    assert (X != 0).any()
