@@ -368,14 +368,15 @@ def main():
                 # queries here).  The candidate filter no longer gathers candidate rows: one contraction of all
                 # queries against the whole fp16 image reads the matrix ONCE, so the group's longest kernel is bound
                 # by the matrix cores, and that is the roof quoted.  Beside it: the bytes the group is defined to move
-                # (fp16 matrix once + scores out and back in for the candidates + hyperplanes of the traversal + fp32
-                # rows of the survivors, ~2k per query) against the HBM peak.
+                # (fp16 matrix once + scores out and back in for the candidates + the forest's hyperplanes once -- the
+                # traversals' re-reads of them are served by L2 -- + fp32 rows of the survivors, ~2k per query) against
+                # the HBM peak.
                 f = tms.get("query_filter", {"ms": 0, "bytes": 0})
                 if f["ms"] > 0:
                     tfl = f["bytes"] / 1e12 / (f["ms"] / 1e3)
                     cand_rows = tm["bytes"] / (4.0 * D)            # hyperplane dots + candidates + 1, all queries, all steps
                     defined = n_steps * (2.0 * dpad_of(D) * n_items + 4.0 * Q * n_items) + 4.0 * cand_rows \
-                        + n_steps * Q * 4.0 * dpad_of(D) * (T + 8 + 2 * k + 1)
+                        + n_steps * (Q * 4.0 * dpad_of(D) * (2 * k + 1) + 4.0 * dpad_of(D) * st["n_split"])
                     g.update(bound="mfma", achieved=tfl, peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s", frac=tfl / MFMA_F16_PEAK_TFLOPS,
                              ms_per_launch=f["ms"] / max(f["launches"], 1), flops_per_launch=f["bytes"] // max(f["launches"], 1),
                              group_ms_per_launch=tm["ms"] / launches,
@@ -386,7 +387,8 @@ def main():
             if tj:
                 ks = [v for kk, v in tj["kernels"].items() if kk.startswith(kernels_of[name])]
                 if ks:   # bytes past L2 per timed launch group, from separate rocprofv3 --pmc passes
-                    g["traffic"] = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in ks) / max(tm["launches"] // max(n_steps, 1), 1)
+                    g["traffic"] = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in ks) / max(tj.get("steps", 1), 1) \
+                        / max(tm["launches"] // max(n_steps, 1), 1)
                     g["traffic_source"] = tj_name + " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
             if g["frac"] > 1.0:
                 raise SystemExit("bench.py: roofline fraction %.2f > 1 for %s -- the bytes or the peak are wrong" % (g["frac"], name))
