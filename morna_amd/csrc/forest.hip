@@ -859,8 +859,20 @@ __host__ __device__ inline bool sides_stand(int attempt, int64_t n0, int64_t n1)
 // not stand is left alone (its next attempt, or the fallback, partitions it).
 // inv (may be null): inv[tree][item] = position of the item in the tree's permutation, kept current here -- what the
 // matrix-core split looks a row's node up with (one look-up per (row, tree), no separate inversion pass per level).
-// host_counts (page-locked host memory, may be null): the task's right-side count goes there first thing, tagged with the
-// level's epoch, so that the host's bookkeeping for the next attempt or level runs while the partition does.
+// The right-side counts of a level's tasks, posted to page-locked host memory tagged with the call's epoch: a launch of its
+// own in front of the partition, so that ALL counts are with the host a few microseconds after the split and its
+// bookkeeping for the next attempt or level runs while the partition does (posted by the partition workgroups themselves,
+// the last counts arrived when the last workgroups started, near the partition's end: 20-65 us of idle device per level).
+__global__ void post_counts_kernel(const int32_t *__restrict__ ones, int32_t n, unsigned long long *__restrict__ host_counts,
+                                   uint32_t epoch)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // relaxed: the word carries everything the host reads (a release here would write back this CU's whole L2 share)
+    if (i < n)
+        __hip_atomic_store(&host_counts[i], ((unsigned long long)epoch << 32) | (unsigned int)ones[i], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <int PT>
 __global__ __launch_bounds__(PT) void partition_kernel(const SplitTask *__restrict__ tasks, int64_t n_items,
                                                        const uint8_t *__restrict__ side,
@@ -872,11 +884,8 @@ __global__ __launch_bounds__(PT) void partition_kernel(const SplitTask *__restri
     const SplitTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const int n1 = ones[blockIdx.x], n0 = t.count - n1;
-    if (host_counts && tid == 0) {
-        // relaxed: the word carries everything the host reads (a release here would write back this CU's whole L2 share)
-        __hip_atomic_store(&host_counts[blockIdx.x], ((unsigned long long)epoch << 32) | (unsigned int)n1, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    (void)host_counts;
+    (void)epoch;
     if (!sides_stand(t.attempt, n0, n1)) return;   // uniform over the workgroup
     const int64_t base = (int64_t)t.tree * n_items + t.start;
     // PT_PER consecutive positions per thread and round: a round costs two barriers whatever it moves, and with one
@@ -1099,6 +1108,8 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 memset(h->host_counts, 0, h->host_counts_cap * 8);
             }
             const uint32_t epoch = ++h->count_epoch ? h->count_epoch : ++h->count_epoch;   // never 0: the mailbox starts zeroed
+            hipLaunchKernelGGL(post_counts_kernel, dim3((unsigned)((A + 255) / 256)), dim3(256), 0, h->stream, d_ones.p, A, h->host_counts,
+                               epoch);
             {
                 ScopedTimer tm(h, MORNA_T_PARTITION, 0);
                 if (level_rows >= (int64_t)A * 2048)
