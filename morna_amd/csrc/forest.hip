@@ -24,9 +24,11 @@
 //   split_rw_kernel   the same work at shallow levels (<= 4 split nodes per tree) as
 //                     row windows x tree groups: a row is loaded once into registers
 //                     and used for every tree of the group (runs with MORNA_SPLIT_MM=0).
+//   post_counts_kernel  the level's right-side counts into a page-locked mailbox the host polls
 //   (host)            annoy's 3-attempt / 0.95 imbalance rule on the counts
 //   fallback_kernel   random sides for nodes still above 0.99
-//   partition_kernel  stable partition of each segment by side
+//   partition_kernel  stable partition of each segment by side; keeps inv[tree][item], the item's position in the tree,
+//                     current (what the matrix-core split finds a row's node with)
 // Node ids are handed out breadth-first, children of the i-th split node of a
 // level get consecutive ids, exactly as oracle mode 1 does.
 #include <algorithm>
@@ -877,15 +879,12 @@ template <int PT>
 __global__ __launch_bounds__(PT) void partition_kernel(const SplitTask *__restrict__ tasks, int64_t n_items,
                                                        const uint8_t *__restrict__ side,
                                                        const int32_t *__restrict__ ones, int32_t *__restrict__ perm,
-                                                       int32_t *__restrict__ tmp, int32_t *__restrict__ inv,
-                                                       unsigned long long *__restrict__ host_counts, uint32_t epoch)
+                                                       int32_t *__restrict__ tmp, int32_t *__restrict__ inv)
 {
     __shared__ int s_w1[PT / WAVE];
     const SplitTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const int n1 = ones[blockIdx.x], n0 = t.count - n1;
-    (void)host_counts;
-    (void)epoch;
     if (!sides_stand(t.attempt, n0, n1)) return;   // uniform over the workgroup
     const int64_t base = (int64_t)t.tree * n_items + t.start;
     // PT_PER consecutive positions per thread and round: a round costs two barriers whatever it moves, and with one
@@ -1114,10 +1113,10 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 ScopedTimer tm(h, MORNA_T_PARTITION, 0);
                 if (level_rows >= (int64_t)A * 2048)
                     hipLaunchKernelGGL(partition_kernel<1024>, dim3((unsigned)A), dim3(1024), 0, h->stream, d_tasks.p, N, side.p,
-                                       d_ones.p, h->perm.p, tmp.p, inv_p, h->host_counts, epoch);
+                                       d_ones.p, h->perm.p, tmp.p, inv_p);
                 else
                     hipLaunchKernelGGL(partition_kernel<256>, dim3((unsigned)A), dim3(256), 0, h->stream, d_tasks.p, N, side.p,
-                                       d_ones.p, h->perm.p, tmp.p, inv_p, h->host_counts, epoch);
+                                       d_ones.p, h->perm.p, tmp.p, inv_p);
             }
             if (hipGetLastError() != hipSuccess) {
                 set_error("forest build: partition launch failed");
