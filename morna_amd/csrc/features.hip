@@ -259,18 +259,25 @@ __global__ void flags_to_serial_kernel(uint8_t *__restrict__ flag, int64_t J)
 // Branch-free over the NU register sets -- every load of a phase is in flight before the first result is used; entries
 // past the end of the line re-read its first entry and are masked afterwards.
 template <int TILE_SHIFT, int NU>
-__device__ inline void line_prep_piece(const int32_t *__restrict__ ids, const int32_t *__restrict__ rank, int64_t b, int32_t len,
-                                       int32_t c0, int32_t n_tiles, int32_t *__restrict__ off, int32_t *__restrict__ pid,
+__device__ inline void line_prep_piece(const int32_t *__restrict__ ids, const int32_t *__restrict__ rank, int32_t n_items, int64_t b,
+                                       int32_t len, int32_t c0, int32_t n_tiles, int32_t *__restrict__ off, int32_t *__restrict__ pid,
                                        int lane, bool &asc, int32_t &prev_last)
 {
     int32_t p[NU];
+    bool bad = false;   // an id outside [0, n_items): such an entry has no cell (the tile-by-tile form skips it the same way)
 #pragma unroll
     for (int u = 0; u < NU; u++) {
         const int32_t e = c0 + u * WAVE + lane;
         p[u] = ids[b + (e < len ? e : c0)];
     }
 #pragma unroll
-    for (int u = 0; u < NU; u++) p[u] = rank[p[u]];
+    for (int u = 0; u < NU; u++) {
+        const bool ok = (uint32_t)p[u] < (uint32_t)n_items;
+        bad |= !ok;
+        const int32_t r = rank[ok ? p[u] : 0];
+        p[u] = ok ? r : -1;
+    }
+    if (__any(bad)) asc = false;   // the line takes the scanned path, where a position of -1 falls into no tile
 #pragma unroll
     for (int u = 0; u < NU; u++) {
         const int32_t e = c0 + u * WAVE + lane;
@@ -303,7 +310,7 @@ __device__ inline void line_prep_piece(const int32_t *__restrict__ ids, const in
 
 template <int TILE_SHIFT>
 __global__ __launch_bounds__(256) void line_prep_kernel(const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ ids,
-                                                        const int32_t *__restrict__ rank, int64_t J, int32_t n_tiles,
+                                                        const int32_t *__restrict__ rank, int32_t n_items, int64_t J, int32_t n_tiles,
                                                         int32_t *__restrict__ tile_off /* [J][n_tiles + 1] */,
                                                         int32_t *__restrict__ pid /* [nnz] position of each entry's item */,
                                                         uint8_t *__restrict__ flag)
@@ -319,16 +326,16 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const int64_t *__restric
         for (int32_t c0 = 0; c0 < len;) {
             const int32_t left = len - c0;   // uniform: the piece takes the smallest register set that holds what is left
             if (left > WAVE * 24) {
-                line_prep_piece<TILE_SHIFT, 32>(ids, rank, b, len, c0, n_tiles, off, pid, lane, asc, prev_last);
+                line_prep_piece<TILE_SHIFT, 32>(ids, rank, n_items, b, len, c0, n_tiles, off, pid, lane, asc, prev_last);
                 c0 += WAVE * 32;
             } else if (left > WAVE * 16) {
-                line_prep_piece<TILE_SHIFT, 24>(ids, rank, b, len, c0, n_tiles, off, pid, lane, asc, prev_last);
+                line_prep_piece<TILE_SHIFT, 24>(ids, rank, n_items, b, len, c0, n_tiles, off, pid, lane, asc, prev_last);
                 c0 += WAVE * 24;
             } else if (left > WAVE * 8) {
-                line_prep_piece<TILE_SHIFT, 16>(ids, rank, b, len, c0, n_tiles, off, pid, lane, asc, prev_last);
+                line_prep_piece<TILE_SHIFT, 16>(ids, rank, n_items, b, len, c0, n_tiles, off, pid, lane, asc, prev_last);
                 c0 += WAVE * 16;
             } else {
-                line_prep_piece<TILE_SHIFT, 8>(ids, rank, b, len, c0, n_tiles, off, pid, lane, asc, prev_last);
+                line_prep_piece<TILE_SHIFT, 8>(ids, rank, n_items, b, len, c0, n_tiles, off, pid, lane, asc, prev_last);
                 c0 += WAVE * 8;
             }
         }
@@ -853,7 +860,7 @@ int build_features(morna_index *h, int64_t n_items)
                 // not ascend only (none, for a file whose lines are sorted and an order that says so)
                 const int lp_blocks = (int)std::max<int64_t>(1, std::min<int64_t>((J + 3) / 4, (int64_t)h->n_cus * 8));
                 hipLaunchKernelGGL(line_prep_kernel<AW_TILE_SHIFT>, dim3(lp_blocks), dim3(256), 0, h->stream2, h->s_row_ptr.p,
-                                   h->s_ids.p, h->item_rank.p, J, aw_tiles, tile_off.p, pid.p, flags.p);
+                                   h->s_ids.p, h->item_rank.p, (int32_t)n_items, J, aw_tiles, tile_off.p, pid.p, flags.p);
             }
             if (n_words <= LFW_MAX_WORDS) {
                 const size_t lds = (size_t)LFW_WAVES * (size_t)n_words * 4;

@@ -495,3 +495,34 @@ def test_feature_build_norms_are_canonical(capi, D, order):
     want = np.array([capi.dot(1, x, x) for x in X], np.float32)
     assert n2.tobytes() == want.tobytes()
     assert (X != 0).any()
+
+
+def test_feature_build_ignores_ids_past_n_items():
+    """Entries whose internal id is not below the n_items of build_features have no cell: both forms of the accumulation
+    skip them (the one that looks positions up in the item order must not read past its table)."""
+    from morna_amd.annoy import AnnoyIndex
+    rng = np.random.default_rng(8)
+    D, n_items, J = 64, 300, 120
+    keys = ["chr1 %d %d" % (i, i + 5) for i in range(J)]
+    kb = [k.encode() for k in keys]
+    key_off = np.zeros(J + 1, np.int64)
+    key_off[1:] = np.cumsum([len(k) for k in kb])
+    rp, ids, cov = [0], [], []
+    for j in range(J):
+        line = np.sort(rng.choice(n_items + 50, size=int(rng.integers(5, 80)), replace=False))   # some ids in [300, 350)
+        ids += line.tolist()
+        cov += rng.integers(1, 9, size=len(line)).tolist()
+        rp.append(len(ids))
+    args = (np.frombuffer(b"".join(kb), np.uint8), key_off, np.array(rp, np.int64), np.array(ids, np.int32), np.array(cov, np.int32),
+            rng.random(J) + 0.5)
+    out = []
+    for order in (None, np.arange(n_items, dtype=np.int64), np.arange(n_items, dtype=np.int64)[::-1].copy()):
+        a = AnnoyIndex(D)
+        a.stage_junctions(*args)
+        if order is not None:
+            a.stage_item_order(order)
+        a.build_features(n_items)
+        out.append(a.get_items())
+    assert out[0].tobytes() == out[1].tobytes() == out[2].tobytes()
+    keep = np.array(ids) < n_items
+    assert (out[0] != 0).any() and keep.sum() < len(ids)
