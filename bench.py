@@ -146,6 +146,55 @@ def exact_all_pairs_shard(args, device):
                          "host_copy_note": "wall_ms includes the host <-> device copies of queries and results"}}
 
 
+def sharded_overhead(args, index, n_items, items, k, step):
+    """What the row-sharded query path costs over the plain one when there is one shard: the same step with the queries
+    going through ShardedSearch on a 1-rank RCCL group (query rows all-gathered in HBM, answers packed in HBM, all-gather,
+    merge kernel).  Extra key; the N > 1 runs are the driver's."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from morna_amd.dist import ShardedSearch
+    if dist.is_initialized():
+        return None
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    # RCCL prints a version banner on stdout when it starts: this run's stdout is ONE JSON line, so the banner goes to stderr
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                device_id=torch.device("cuda", torch.cuda.current_device()))
+    except Exception as e:      # no RCCL in this environment: the key says so
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+        return {"error": str(e)[:200]}
+    try:
+        ss = ShardedSearch(index, 0, 1, n_items)
+        n = 10
+
+        def run(fn):
+            for _ in range(2):
+                fn()
+            index.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            index.synchronize()
+            return 1e3 * (time.perf_counter() - t0) / n
+        plain = run(lambda: index.get_nns_by_item_batch(items, k, args.search_k))
+        shard = run(lambda: ss.get_nns_by_local_items(items, k, args.search_k, n_each=[len(items)]))
+        return {"plain_query_ms": plain, "sharded_query_ms": shard, "overhead_ms": shard - plain,
+                "path": "query rows all-gathered HBM -> HBM, per-shard top-k packed in HBM, RCCL all_gather_into_tensor, merge kernel"}
+    finally:
+        dist.destroy_process_group()
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+
+
 def cpu_baseline(args, data, prep, items):
     """Oracle (port of morna.py + annoy, 1 thread) on a bounded sample, extrapolated."""
     from oracle import capi
@@ -245,7 +294,9 @@ def main():
     t_stage = time.perf_counter() - t_stage
     items = query_items(n_items, Q)              # the queries this rank owns (all of them when world == 1)
     sharded = ShardedSearch(index, rank, world, n_items) if (world > 1 or force_sharded) else None
+    n_each = None
     if sharded is not None:
+        n_each = [len(items[g::world]) for g in range(world)]   # every rank knows every rank's share of the queries
         items = items[rank::world]
 
     def step(split=False):
@@ -260,7 +311,7 @@ def main():
         if sharded is None:
             res = index.get_nns_by_item_batch(items, k, args.search_k)
         else:
-            res = sharded.get_nns_by_local_items(items, k, args.search_k)
+            res = sharded.get_nns_by_local_items(items, k, args.search_k, n_each=n_each)
         t2 = time.perf_counter()
         return t1 - t0, t2 - t1, res
 
@@ -438,6 +489,8 @@ def main():
             out["recall_at_k_vs_exact"] = float(rec)
         if world == 1 and not args.no_extras:
             out["exact_all_pairs_shard"] = exact_all_pairs_shard(args, local_rank)
+            if sharded is None:
+                out["sharded_path_at_world_1"] = sharded_overhead(args, index, n_items, items, k, step)
         if world == 1 and not args.no_cpu_baseline:
             prep["X_host"] = index.get_items()
             out["cpu_baseline"] = cpu_baseline(args, data, prep, items)

@@ -150,13 +150,17 @@ class ShardedSearch(object):
         failed = (self._all_gather_np(np.ascontiguousarray(cnt, np.int32)) < 0).any(axis=0)
         return out_ids, out_d, np.where(failed, -1, counts).astype(np.int32)
 
-    def get_nns_by_local_items(self, items, k, search_k=-1):
+    def get_nns_by_local_items(self, items, k, search_k=-1, n_each=None):
         """Each rank contributes the rows of some of its own items as queries
         (the by-item form, morna.py:762); every rank gets the answers to all of them,
-        ordered rank 0's queries first."""
-        n_each = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(self.world)]
-        dist.all_gather(n_each, torch.tensor([len(items)], dtype=torch.int64, device=self.device), group=self.group)
-        n_each = [int(x.item()) for x in n_each]
+        ordered rank 0's queries first.  n_each: how many queries each rank contributes, when the caller
+        knows (saves the exchange of the counts, a latency-bound collective per call)."""
+        if n_each is None:
+            n_each = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(self.world)]
+            dist.all_gather(n_each, torch.tensor([len(items)], dtype=torch.int64, device=self.device), group=self.group)
+            n_each = [int(x.item()) for x in n_each]
+        elif len(n_each) != self.world or n_each[self.rank] != len(items):
+            raise ValueError("n_each must list every rank's query count, this rank's being len(items)")
         n_max = max(n_each)
         f = self.index.f
         if self.device.type == "cuda" and hasattr(self.index, "get_nns_by_vector_ptr"):
