@@ -44,7 +44,9 @@ namespace morna {
 
 #define TM_THREADS 256
 #define TM_ITERS 200
+#ifndef TM_STRIP_DEPTH
 #define TM_STRIP_DEPTH 4   // rows in flight per node in two_means_strip_kernel
+#endif
 
 // ------------------------------------------------------------------ two_means
 
