@@ -43,35 +43,6 @@ namespace {
 
 using morna::set_error;
 
-struct LineReader {
-    gzFile f = nullptr;
-    std::vector<char> buf;
-    bool open(const char *path)
-    {
-        f = gzopen(path, "rb");   // transparently reads plain text too
-        if (!f) return false;
-        gzbuffer(f, 1 << 20);
-        buf.resize(1 << 16);
-        return true;
-    }
-    // next line without its terminator; false at EOF
-    bool next(std::string &line)
-    {
-        line.clear();
-        for (;;) {
-            if (!gzgets(f, buf.data(), (int)buf.size())) return !line.empty();
-            size_t n = strlen(buf.data());
-            line.append(buf.data(), n);
-            if (n && buf[n - 1] == '\n') return true;
-            if (gzeof(f)) return !line.empty();
-        }
-    }
-    ~LineReader()
-    {
-        if (f) gzclose(f);
-    }
-};
-
 inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
 
 // Python's line.strip(): [b, e) without leading / trailing whitespace
