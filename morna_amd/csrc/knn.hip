@@ -444,11 +444,9 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
                  s_bm = bm_lds ? 0 : align_up((size_t)batch * bm_words * 4, 256),
                  s_ids = align_up((size_t)batch * k * 4, 256),
                  s_scores = may_dense ? align_up((size_t)batch * N * 4, 256) : 0;
-    MORNA_TRY(h->ws.alloc(s_pq + s_keys + s_q + s_q16 + 6 * s_qf + 2 * s_cand + s_bm + 2 * s_ids + s_scores));
+    MORNA_TRY(h->ws.alloc(s_pq + s_keys + s_q + s_q16 + 7 * s_qf + 2 * s_cand + s_bm + 2 * s_ids + s_scores));
     MORNA_TRY(h->d_stat.alloc(4));
     if (use_filter) MORNA_TRY(split_mm_prepare_rows(h, h->stream));
-    DevBuf<int32_t> d_items;
-    if (items_host) MORNA_TRY(d_items.alloc((size_t)batch));
 
     for (int64_t q0 = 0; q0 < nq; q0 += batch) {
         const int64_t nb = std::min(batch, nq - q0);
@@ -468,6 +466,7 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
         float *q_e16 = (float *)p; p += s_qf;
         float *q_scale = (float *)p; p += s_qf;
         P.ncand = (int32_t *)p; p += s_qf;
+        int32_t *d_items = (int32_t *)p; p += s_qf;   // (part of the workspace: a hipMalloc / hipFree per call costs tens of microseconds)
         P.cand = (int32_t *)p; p += s_cand;
         P.low = (float *)p; p += s_cand;
         P.bm_global = (uint32_t *)p; p += s_bm;
@@ -496,8 +495,8 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
                                      (size_t)h->dim * 4, (size_t)nb, hipMemcpyDefault, h->stream));
             P.Q = Qd;
         } else {
-            HIP_TRY(hipMemcpyAsync(d_items.p, items_host + q0, (size_t)nb * 4, hipMemcpyHostToDevice, h->stream));
-            P.items = d_items.p;
+            HIP_TRY(hipMemcpyAsync(d_items, items_host + q0, (size_t)nb * 4, hipMemcpyHostToDevice, h->stream));
+            P.items = d_items;
         }
         {
             // algorithmic bytes = 4*D*(hyperplane dots + unique candidates + 1) per
