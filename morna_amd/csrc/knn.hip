@@ -83,6 +83,51 @@ __device__ inline uint64_t block_min_u64(uint64_t v, uint64_t *s_red, int tid)
     return r;
 }
 
+// k-th smallest of n distinct keys (~0 when n < k), the same value in every thread.  While a thread's share of the keys
+// fits KTH_HELD registers and k <= KTH_MAX_K: every wave extracts the k smallest of ITS keys in k rounds of register compares
+// and a wave minimum -- no barrier -- and the k-th smallest of the waves' k-lists is found by counting, one key per lane.
+// Otherwise (and as round 1 did throughout): k rounds of a block-wide minimum over the keys in memory, two barriers each.
+#define KTH_HELD 16
+#define KTH_MAX_K 32
+__device__ inline uint64_t block_kth_smallest(const uint64_t *keys, int n, int k, int tid, uint64_t *s_red, uint64_t *s_top)
+{
+    const int lane = tid & (WAVE - 1), w = tid / WAVE;
+    if (n <= Q_THREADS * KTH_HELD && k <= KTH_MAX_K) {
+        uint64_t held[KTH_HELD];
+#pragma unroll
+        for (int u = 0; u < KTH_HELD; u++) held[u] = tid + Q_THREADS * u < n ? keys[tid + Q_THREADS * u] : ~0ull;
+        uint64_t prev = 0;
+        for (int r = 0; r < k; r++) {
+            uint64_t best = ~0ull;
+#pragma unroll
+            for (int u = 0; u < KTH_HELD; u++)
+                if ((r == 0 || held[u] > prev) && held[u] < best) best = held[u];
+            prev = wave_min_u64(best);
+            if (lane == 0) s_top[w * KTH_MAX_K + r] = prev;   // ~0: this wave has run out of keys
+        }
+        __syncthreads();
+        // Q_WAVES * k keys, k-th smallest: a key's rank is the number of keys below it (the real ones are distinct)
+        uint64_t found = ~0ull;
+        for (int i = tid; i < Q_WAVES * k; i += Q_THREADS) {
+            const uint64_t v = s_top[(i / k) * KTH_MAX_K + i % k];
+            int below = 0;
+            for (int j = 0; j < Q_WAVES * k; j++) below += s_top[(j / k) * KTH_MAX_K + j % k] < v ? 1 : 0;
+            if (v != ~0ull && below == k - 1) found = v;
+        }
+        return block_min_u64(found, s_red, tid);
+    }
+    uint64_t kth = 0;
+    for (int r = 0; r < k; r++) {
+        uint64_t best = ~0ull;
+        for (int c = tid; c < n; c += Q_THREADS) {
+            const uint64_t kk = keys[c];
+            if ((r == 0 || kk > kth) && kk < best) best = kk;
+        }
+        kth = block_min_u64(best, s_red, tid);
+    }
+    return kth;
+}
+
 // ---- traversal: annoy's _get_all_nns up to the candidate set (oracle/annoy_oracle.c:453-504) -------------------
 // One workgroup per query: all root margins (every wave takes trees), then the best-first descent by wave 0 (array
 // priority queue, bitmap de-duplication of the leaves' ids).  Leaves the unique candidates in cand[].
@@ -242,6 +287,7 @@ __global__ __launch_bounds__(Q_THREADS) void query_refine_kernel(QueryParams P)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *qv = (float4 *)smem;
     __shared__ uint64_t s_red[Q_WAVES];
+    __shared__ uint64_t s_top[Q_WAVES * KTH_MAX_K];
     __shared__ int s_nsurv;
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
@@ -323,15 +369,8 @@ __global__ __launch_bounds__(Q_THREADS) void query_refine_kernel(QueryParams P)
             }
         }
         __syncthreads();
-        uint64_t kth = 0;   // the k-th smallest upper bound (keys are distinct: the candidate index is in them)
-        for (int r = 0; r < P.k; r++) {
-            uint64_t best = ~0ull;
-            for (int c = tid; c < ncand; c += Q_THREADS) {
-                const uint64_t kk = keys[c];
-                if ((r == 0 || kk > kth) && kk < best) best = kk;
-            }
-            kth = block_min_u64(best, s_red, tid);
-        }
+        // the k-th smallest upper bound (keys are distinct: the candidate index is in them)
+        const uint64_t kth = block_kth_smallest(keys, ncand, P.k, tid, s_red, s_top);
         const float thr = f32_from_orderable((uint32_t)(kth >> 32));
         // survivors, compacted to the front of keys[] as ids (order is irrelevant: the ranking below is by value)
         __syncthreads();
@@ -357,6 +396,27 @@ __global__ __launch_bounds__(Q_THREADS) void query_refine_kernel(QueryParams P)
     const int kout = P.k < nsel ? P.k : nsel;
     uint64_t prev = 0;
     bool have_prev = false;
+    if (nsel <= WAVE * KTH_HELD) {
+        // few enough for one wave's registers (the usual case: ~2k survivors): k rounds of register compares and a wave
+        // minimum, no barrier
+        if (w == 0) {
+            uint64_t held[KTH_HELD];
+#pragma unroll
+            for (int u = 0; u < KTH_HELD; u++) held[u] = lane + WAVE * u < nsel ? keys[lane + WAVE * u] : ~0ull;
+            for (int r = 0; r < kout; r++) {
+                uint64_t best = ~0ull;
+#pragma unroll
+                for (int u = 0; u < KTH_HELD; u++)
+                    if ((r == 0 || held[u] > prev) && held[u] < best) best = held[u];
+                prev = wave_min_u64(best);
+                if (lane == 0) {
+                    P.ids_out[qi * P.k + r] = (int32_t)(uint32_t)prev;
+                    const float d = f32_from_orderable((uint32_t)(prev >> 32));
+                    P.dist_out[qi * P.k + r] = sqrtf(d > 0.f ? d : 0.f);   // normalized_distance
+                }
+            }
+        }
+    } else
     for (int r = 0; r < kout; r++) {
         uint64_t best = ~0ull;
         for (int c = tid; c < nsel; c += Q_THREADS) {
