@@ -174,7 +174,7 @@ struct morna_index {
     morna::DevBuf<uint8_t> ws;
     // build scratch kept between calls (feature and forest builds reuse it instead of
     // hipMalloc / hipFree on every call); slots are named in features.hip / forest.hip
-    morna::DevBuf<uint8_t> scratch[27];
+    morna::DevBuf<uint8_t> scratch[29];
     // [0] rows read by query kernels (hyperplane dots + candidates + 1 per query)
     morna::DevBuf<unsigned long long> d_stat;
 
@@ -240,7 +240,7 @@ int split_mm_prepare_rows(morna_index *h, hipStream_t stream);   // stream: the 
 int split_mm_convert_rows(morna_index *h, const float *src, int64_t rows, _Float16 *dst, float *norm, float *err,
                           float *inv_scale, hipStream_t stream);
 int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, const float *hp_level,
-                   const int32_t *inv, uint32_t seed, uint8_t *side, int32_t *ones);
+                   const int32_t *perm, const int32_t *inv, uint32_t seed, uint8_t *side, int32_t *ones);
 // packed_dev (device memory, or null): [nq][2k] int32 message of the row-sharded search -- ids + id_offset, distance bits
 int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int32_t *items_host, int64_t nq, int32_t k,
                 int32_t search_k, int32_t *ids_out, float *dist_out, int32_t *count_out, int32_t *packed_dev = nullptr,

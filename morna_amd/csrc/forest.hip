@@ -1252,7 +1252,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             if (side_work) F_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
             if (use_mm) {
                 ScopedTimer tm(h, MORNA_T_SPLIT, 4 * (int64_t)D * (rows + A));
-                if ((rc = split_mm_level(h, d_tasks.p, A, hp_level, inv.p, seed, side.p, d_ones.p))) {
+                if ((rc = split_mm_level(h, d_tasks.p, A, hp_level, h->perm.p, inv.p, seed, side.p, d_ones.p))) {
                     cleanup();
                     return rc;
                 }

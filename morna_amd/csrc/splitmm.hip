@@ -102,46 +102,76 @@ __global__ __launch_bounds__(BIG ? 1024 : 512) void split_mm_kernel(
     const _Float16 *__restrict__ H16, const float *__restrict__ hn, const float *__restrict__ he, int32_t n_tasks,
     const SplitTask *__restrict__ tasks, const int32_t *__restrict__ inv /* [tree][item] position in the tree's permutation */,
     float eps, uint8_t *__restrict__ side, int32_t *__restrict__ ones, unsigned int *__restrict__ amb_count,
-    int2 *__restrict__ amb, unsigned int amb_cap)
+    int2 *__restrict__ amb, unsigned int amb_cap,
+    const int32_t *__restrict__ col_list /* [row tiles][n_tasks] the tasks each row tile needs, ascending; null: all of them */,
+    const int32_t *__restrict__ col_count /* [row tiles] */,
+    const int32_t *__restrict__ col_first /* [row tiles + 1] workgroups (chunks of COLS tasks) before each row tile */)
 {
     constexpr int ROWS = BIG ? 256 : 128, COLS = ROWS, THREADS = BIG ? 1024 : 512;
     // dynamic LDS: during the contraction the stages of operand slabs, afterwards the result, 128 hyperplanes x ROWS rows at
     // a time (BIG: the two halves of the hyperplane tile in turn)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *Cs = (float *)smem;
-    __shared__ int s_ones[COLS], s_tree[COLS], s_start[COLS], s_end[COLS];
+    __shared__ int s_ones[COLS], s_tree[COLS], s_start[COLS], s_end[COLS], s_task[COLS];
     __shared__ float s_hn[COLS], s_he[COLS];
     __shared__ int2 s_open[SM_OPEN];   // pairs this tile's filter left open
     __shared__ int s_nopen;
     __shared__ unsigned int s_obase;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
-    // Workgroup b runs on XCD b % 8.  An XCD takes every 8th row tile and walks that tile's hyperplane tiles
+    // Workgroup b runs on XCD b % 8.  Without lists an XCD takes every 8th row tile and walks that tile's hyperplane tiles
     // back to back: the row tile (786 KB at D = 3000) is fetched from HBM once and then served by that XCD's
-    // L2; the level's hyperplanes (a few MB) stay in the Infinity Cache for everybody.
+    // L2; the level's hyperplanes (a few MB) stay in the Infinity Cache for everybody.  With lists the (row tile, chunk
+    // of its list) pairs, in row-tile order, are cut into 8 runs of equal length, one per XCD (col_first[tile] = pairs
+    // before the tile): the same locality, and the XCDs finish together although the lists differ in length.
     const int n_ct = (n_tasks + COLS - 1) / COLS;
-    const int64_t row_tile = (int64_t)((blockIdx.x >> 3) / n_ct) * 8 + (blockIdx.x & 7);
+    int64_t row_tile;
+    int c0;
+    if (col_list) {
+        const int n_rt = (int)((n_items + ROWS - 1) / ROWS);
+        const int total = col_first[n_rt], run = (total + 7) / 8;
+        const int slot = (int)(blockIdx.x >> 3), g = (int)(blockIdx.x & 7) * run + slot;
+        if (slot >= run || g >= total) return;
+        int lo = 0, hi = n_rt - 1;   // the last tile with col_first[tile] <= g
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (col_first[mid] <= g) lo = mid;
+            else hi = mid - 1;
+        }
+        row_tile = lo;
+        c0 = (g - col_first[lo]) * COLS;
+    } else {
+        row_tile = (int64_t)((blockIdx.x >> 3) / n_ct) * 8 + (blockIdx.x & 7);
+        c0 = (int)((blockIdx.x >> 3) % n_ct) * COLS;
+    }
     const int64_t r0 = row_tile * ROWS;
-    const int c0 = (int)((blockIdx.x >> 3) % n_ct) * COLS;
     if (r0 >= n_items) return;
-
+    // the tasks (hyperplanes) of this workgroup: COLS consecutive ones of the level, or of the row tile's own list -- the
+    // tasks that hold at least one of its rows (split_active_*_kernel).  Either way they ascend: a tree's tasks are
+    // neighbours and sorted by start.
+    const int n_mine = col_list ? col_count[row_tile] : n_tasks;
+    if (c0 >= n_mine) return;   // uniform
+    const int n_valid = n_mine - c0 < COLS ? n_mine - c0 : COLS;
     if (tid < COLS) {
-        const int col = c0 + tid < n_tasks ? c0 + tid : n_tasks - 1;
+        const int k = c0 + (tid < n_valid ? tid : n_valid - 1);
+        const int col = col_list ? col_list[row_tile * n_tasks + k] : k;
         const SplitTask t = tasks[col];
         s_ones[tid] = 0;
         if (tid == 0) s_nopen = 0;
+        s_task[tid] = col;
         s_tree[tid] = t.tree;
         s_start[tid] = t.start;
         s_end[tid] = t.start + t.count;
         s_hn[tid] = hn[col];
         s_he[tid] = he[col];
     }
+    __syncthreads();   // the delivery addresses below come from s_task
     // the contraction (mm16.hpp): hyperplanes are the A side (m) and the rows the B side (n), so the result has a
     // row of X on the lane and the epilogue's look-ups and side bytes of a wave run along consecutive rows; rows
     // past the end repeat the last one: their products are never looked up
     constexpr int NB = BIG ? 2 : 1;
     f32x16 acc[NB][2];
     auto b_row = [&](int rt) { return r0 + rt < n_items ? r0 + rt : n_items - 1; };
-    auto a_row = [&](int rt) { return (int64_t)(c0 + rt < n_tasks ? c0 + rt : n_tasks - 1); };
+    auto a_row = [&](int rt) { return (int64_t)s_task[rt]; };
     if constexpr (BIG) mm16_tile_256x256<64, 2>(X16, H16, dpad, smem, b_row, a_row, acc);   // (4 stages of 32 halfs, three deliveries in flight: 0.62 / 0.73 ms against 0.57 / 0.66 at C3)
     else mm16_tile<128, 64, 2>(X16, H16, dpad, smem, b_row, a_row, acc);
     const int lr = lane & 31, lh = lane >> 5;
@@ -167,12 +197,12 @@ __global__ __launch_bounds__(BIG ? 1024 : 512) void split_mm_kernel(
                         Cs[((wn & 1) * 64 + tn * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * ROWS + wm * 32 * NB + tb * 32 + lr] = acc[tb][tn][e];
         }
         __syncthreads();
-        const int c_lo = c0 + half * 128;
-        if (c_lo >= n_tasks) break;   // uniform
+        const int c_lo = half * 128;   // (indices into the workgroup's task tables)
+        if (c_lo >= n_valid) break;   // uniform
         // A row needs ONE entry per tree: that of its node.  A wave takes 64 consecutive rows and one tree at a
         // time: the task look-up, the position look-up and the side bytes all run along consecutive rows.
-        const int c_hi = (c_lo + 128 < n_tasks ? c_lo + 128 : n_tasks);   // tasks [c_lo, c_hi) are this pass's
-        const int t_first = s_tree[c_lo - c0], t_last = s_tree[c_hi - 1 - c0];
+        const int c_hi = (c_lo + 128 < n_valid ? c_lo + 128 : n_valid);   // tasks [c_lo, c_hi) are this pass's
+        const int t_first = s_tree[c_lo], t_last = s_tree[c_hi - 1];
         constexpr int EU = BIG ? 4 : 8, TSTEP = THREADS / ROWS;   // trees per batch and thread (BIG: the other half of the result is still in registers); trees between a thread's steps
         for (int tb = t_first + tid / ROWS; tb <= t_last; tb += EU * TSTEP) {
             // the look-ups of a batch are issued together: where the row stands in each tree's permutation
@@ -194,14 +224,14 @@ __global__ __launch_bounds__(BIG ? 1024 : 512) void split_mm_kernel(
                 int lo = -1, n_t = 0;
 #pragma unroll
                 for (int k = 0; k < COLS / WAVE; k++) {
-                    const uint64_t mk = __ballot(c0 + k * WAVE + lane < n_tasks && s_tree[k * WAVE + lane] == tr);
+                    const uint64_t mk = __ballot(k * WAVE + lane < n_valid && s_tree[k * WAVE + lane] == tr);
                     if (mk && lo < 0) lo = k * WAVE + (int)__builtin_ctzll(mk);
                     n_t += (int)__builtin_popcountll(mk);
                 }
                 int before = 0;
                 for (int j = 0; j < n_t; j++) before += s_start[lo + j] <= pp[u] ? 1 : 0;
                 if (pp[u] >= 0 && before > 0 && pp[u] < s_end[lo + before - 1]) {
-                    a[u] = c0 + lo + before - 1;
+                    a[u] = lo + before - 1;
                     pos[u] = pp[u] - s_start[lo + before - 1];
                 }
             }
@@ -209,7 +239,7 @@ __global__ __launch_bounds__(BIG ? 1024 : 512) void split_mm_kernel(
             for (int u = 0; u < EU; u++) {
                 const int tr = tb + u * TSTEP;
                 const bool mine = a[u] >= c_lo && a[u] < c_hi;
-                const int cl = mine ? a[u] - c0 : 0;   // index into the tile's task tables
+                const int cl = mine ? a[u] : 0;   // index into the workgroup's task tables
                 const float c = Cs[(mine ? a[u] - c_lo : 0) * ROWS + (tid & (ROWS - 1))];   // bank = row: no conflict whatever the nodes are
                 // false for NaN and for rows / hyperplanes that could not be scaled (norm = +inf)
                 const bool decided = mine && fabsf(c) > xa * s_hn[cl] + xb * s_he[cl];
@@ -237,10 +267,10 @@ __global__ __launch_bounds__(BIG ? 1024 : 512) void split_mm_kernel(
                     const int idx = base + (int)__builtin_popcountll(om & ((1ull << lane) - 1ull));
                     if (open) {
                         if (idx < SM_OPEN) {
-                            s_open[idx] = make_int2((int)row, a[u]);
+                            s_open[idx] = make_int2((int)row, s_task[cl]);
                         } else {   // more than the LDS list holds: straight to the global list
                             const unsigned int g = atomicAdd(amb_count, 1u);
-                            if (g < amb_cap) amb[g] = make_int2((int)row, a[u]);
+                            if (g < amb_cap) amb[g] = make_int2((int)row, s_task[cl]);
                         }
                     }
                 }
@@ -256,7 +286,73 @@ __global__ __launch_bounds__(BIG ? 1024 : 512) void split_mm_kernel(
             if (s_obase + i < amb_cap) amb[s_obase + i] = s_open[i];
     }
     __syncthreads();
-    if (tid < COLS && c0 + tid < n_tasks && s_ones[tid]) atomicAdd(&ones[c0 + tid], s_ones[tid]);
+    if (tid < n_valid && s_ones[tid]) atomicAdd(&ones[s_task[tid]], s_ones[tid]);
+}
+
+// ---- which tasks does a row tile need? ------------------------------------------------------------
+// A row is in ONE node per tree, and rows that are neighbours by id tend to be neighbours in the data (ids are
+// handed out in the order samples first appear in the junction lines), so deep in the forest a tile of 256 rows meets only
+// part of the level's split nodes.  active[tile][task] = 1 when some row of the tile is in the task's node; the lists
+// made from it (ascending task numbers) are what split_mm_kernel multiplies the tile with.  One workgroup per task walks
+// the node's slice of the permutation; the byte stores need no atomics.
+__global__ __launch_bounds__(256) void split_active_mark_kernel(const SplitTask *__restrict__ tasks,
+                                                                const int32_t *__restrict__ perm, int64_t n_items,
+                                                                int tile_shift, int32_t n_tasks, uint8_t *__restrict__ active)
+{
+    const SplitTask t = tasks[blockIdx.x];
+    const int32_t *items = perm + (int64_t)t.tree * n_items + t.start;
+    // a node's items ascend (stable partitions of the identity): only the first item of a run in the same tile stores
+    for (int i = threadIdx.x; i < t.count; i += 256) {
+        const int tile = items[i] >> tile_shift;
+        if (i == 0 || (items[i - 1] >> tile_shift) != tile) active[(int64_t)tile * n_tasks + blockIdx.x] = 1;
+    }
+}
+
+// one workgroup per row tile: the marked tasks in ascending order, and how many
+__global__ __launch_bounds__(256) void split_active_list_kernel(const uint8_t *__restrict__ active, int32_t n_tasks,
+                                                                int32_t *__restrict__ col_list, int32_t *__restrict__ col_count)
+{
+    __shared__ int s_wave[4];
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    const uint8_t *a = active + (int64_t)blockIdx.x * n_tasks;
+    int32_t *out = col_list + (int64_t)blockIdx.x * n_tasks;
+    int base = 0;
+    for (int c = 0; c < n_tasks; c += 256) {
+        const bool on = c + (int)threadIdx.x < n_tasks && a[c + threadIdx.x] != 0;
+        const uint64_t m = __ballot(on);
+        if (lane == 0) s_wave[w] = (int)__builtin_popcountll(m);
+        __syncthreads();
+        int before = base;
+        for (int k = 0; k < w; k++) before += s_wave[k];
+        if (on) out[before + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = c + (int)threadIdx.x;
+        base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) col_count[blockIdx.x] = base;
+}
+
+// col_first[tile] = chunks of `cols` tasks in the lists of the tiles before it (one workgroup; n_rt is a few hundred)
+__global__ __launch_bounds__(1024) void split_active_scan_kernel(const int32_t *__restrict__ col_count, int32_t n_rt, int32_t cols,
+                                                                 int32_t *__restrict__ col_first)
+{
+    __shared__ int s_part[1024];
+    const int per = (n_rt + 1023) / 1024, b = threadIdx.x * per;
+    int sum = 0;
+    for (int i = b; i < b + per && i < n_rt; i++) sum += (col_count[i] + cols - 1) / cols;
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = s_part[threadIdx.x] - sum;
+    for (int i = b; i < b + per && i < n_rt; i++) {
+        col_first[i] = run;
+        run += (col_count[i] + cols - 1) / cols;
+    }
+    if (threadIdx.x == 1023) col_first[n_rt] = s_part[1023];
 }
 
 // ---- the pairs the filter left open: canonical fp32 dot, one wave per pair ------------------------
@@ -316,7 +412,7 @@ int split_mm_convert_rows(morna_index *h, const float *src, int64_t rows, _Float
 }
 
 int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, const float *hp_level,
-                   const int32_t *inv, uint32_t seed, uint8_t *side, int32_t *ones)
+                   const int32_t *perm, const int32_t *inv, uint32_t seed, uint8_t *side, int32_t *ones)
 {
     const int64_t N = h->n_items;
     ScratchRef<_Float16> x16(h->scratch[19]), h16(h->scratch[21]);
@@ -338,20 +434,39 @@ int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, co
     // 256 x 256 tiles once the level has hyperplane tiles enough for them to fill the chip in even rounds (MORNA_SPLIT_BIG=0:
     // the 128 x 128 form everywhere)
     static const bool big_on = !(getenv("MORNA_SPLIT_BIG") && atoi(getenv("MORNA_SPLIT_BIG")) == 0);
+    // the tasks each row tile needs, from the second level of a tree on (MORNA_SPLIT_LISTS=0: every tile x every task)
+    static const bool lists_on = !(getenv("MORNA_SPLIT_LISTS") && atoi(getenv("MORNA_SPLIT_LISTS")) == 0);
     if (big_on && n_tasks >= 1024) {
         const unsigned n_rt = (unsigned)((N + 255) / 256), n_ct = (unsigned)((n_tasks + 255) / 256);
+        const int32_t *col_list = nullptr, *col_count = nullptr, *col_first = nullptr;
+        if (lists_on) {
+            ScratchRef<uint8_t> active(h->scratch[27]);
+            ScratchRef<int32_t> lists(h->scratch[28]);
+            MORNA_TRY(active.alloc((size_t)n_rt * n_tasks));
+            MORNA_TRY(lists.alloc((size_t)n_rt * n_tasks + 2 * n_rt + 1));
+            HIP_TRY(hipMemsetAsync(active.p, 0, (size_t)n_rt * n_tasks, h->stream));
+            hipLaunchKernelGGL(split_active_mark_kernel, dim3((unsigned)n_tasks), dim3(256), 0, h->stream, d_tasks, perm, N, 8, n_tasks,
+                               active.p);
+            hipLaunchKernelGGL(split_active_list_kernel, dim3(n_rt), dim3(256), 0, h->stream, active.p, n_tasks, lists.p,
+                               lists.p + (size_t)n_rt * n_tasks);
+            col_list = lists.p;
+            col_count = lists.p + (size_t)n_rt * n_tasks;
+            hipLaunchKernelGGL(split_active_scan_kernel, dim3(1), dim3(1024), 0, h->stream, col_count, (int32_t)n_rt, 256,
+                               lists.p + (size_t)n_rt * n_tasks + n_rt);
+            col_first = col_count + n_rt;
+        }
         const float eps1 = (4.f * (float)h->dpad + 2.f) * 5.9604645e-8f + 4.1e-6f;   // EACC for ONE chain of dpad products
         HIP_TRY(hipFuncSetAttribute((const void *)split_mm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 256 * 4));
         hipLaunchKernelGGL(split_mm_kernel<true>, dim3(8u * ((n_rt + 7) / 8) * n_ct), dim3(1024), 128 * 256 * 4, h->stream, x16.p, xn.p,
                            xn.p + 2 * N, N, h->dpad, h16.p, hn.p, hn.p + n_tasks, n_tasks, d_tasks, inv, eps1, side, ones,
-                           amb_count, amb, (unsigned int)cap);
+                           amb_count, amb, (unsigned int)cap, col_list, col_count, col_first);
     } else {
         const unsigned n_rt = (unsigned)((N + 127) / 128), n_ct = (unsigned)((n_tasks + 127) / 128);
         static_assert(MM16_LDS == 128 * 128 * 4, "the slabs and the result tile share the dynamic LDS");
         HIP_TRY(hipFuncSetAttribute((const void *)split_mm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 4));
         hipLaunchKernelGGL(split_mm_kernel<false>, dim3(8u * ((n_rt + 7) / 8) * n_ct), dim3(512), 128 * 128 * 4, h->stream, x16.p, xn.p,
                            xn.p + 2 * N, N, h->dpad, h16.p, hn.p, hn.p + n_tasks, n_tasks, d_tasks, inv, sm_eps(h->dpad), side,
-                           ones, amb_count, amb, (unsigned int)cap);
+                           ones, amb_count, amb, (unsigned int)cap, (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr);
     }
     hipLaunchKernelGGL(split_amb_kernel, dim3((unsigned)(4 * h->n_cus)), dim3(256), 0, h->stream, h->X.p, N, h->dpad, d_tasks,
                        inv, seed, hp_level, amb_count, amb, (unsigned int)cap, side, ones);
