@@ -185,14 +185,21 @@ int morna_merge_topk(const int64_t *ids, const float *dist, int32_t world, int64
  * The same exchange with the answers resident in HBM (one handle per GPU, RCCL all-gather between the two calls):
  *   morna_get_nns_by_vector_packed  as morna_get_nns_by_vector (q: host or this device's memory), but the answers are
  *       written to packed_dev -- memory of the handle's device, [nq][2k] int32: the k global ids (local id + id_offset,
- *       -1 = empty) followed by the bits of the k fp32 distances: Q * k * 8 bytes per rank.  Complete
- *       when the call returns.
- *   morna_merge_topk_packed  gathered_dev[world][nq][2kk] (the all-gathered messages, device memory, complete before
- *       the call: the library reads it on its own stream) -> the k smallest (distance, id) per query, host memory.
+ *       -1 = empty) followed by the bits of the k fp32 distances: Q * k * 8 bytes per rank.  ENQUEUED on
+ *       the handle's stream when the call returns (q, when it is device memory, is read there too): work the caller
+ *       orders behind that stream sees the message; morna_synchronize() waits for it.
+ *   morna_merge_topk_packed  gathered_dev[world][nq][2kk] (the all-gathered messages, device memory; read on the
+ *       handle's stream: complete before the call, or produced by work ordered on that stream) -> the k smallest
+ *       (distance, id) per query, host memory, complete when the call returns.
+ *   morna_get_item_vectors_dev  rows of `ids` -> out_dev[n][dim] (device memory), enqueued on the handle's stream.
+ *   morna_get_stream  the handle's HIP stream (a hipStream_t), so that the caller can put its collectives between
+ *       these calls in stream order instead of waiting on the host (torch: torch.cuda.ExternalStream).
  * world <= 64, kk <= 255, global ids below 2^31.
  */
 int morna_get_nns_by_vector_packed(morna_index *h, const float *q, int64_t nq, int32_t k, int32_t search_k, int64_t id_offset,
                                    int32_t *packed_dev);
+int morna_get_item_vectors_dev(morna_index *h, const int32_t *ids, int64_t n, float *out_dev);
+int morna_get_stream(morna_index *h, void **stream_out);
 int morna_merge_topk_packed(morna_index *h, const int32_t *gathered_dev, int32_t world, int64_t nq, int32_t kk, int32_t k,
                             int32_t *ids_out, float *dist_out, int32_t *count_out);
 

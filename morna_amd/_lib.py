@@ -50,6 +50,8 @@ SIGNATURES = {
     "morna_merge_topk": (C.c_int, [_p, _p, _i32, _i64, _i32, _i32, _p, _p, _p]),
     "morna_get_nns_by_vector_packed": (C.c_int, [_p, _p, _i64, _i32, _i32, _i64, _p]),
     "morna_merge_topk_packed": (C.c_int, [_p, _p, _i32, _i64, _i32, _i32, _p, _p, _p]),
+    "morna_get_item_vectors_dev": (C.c_int, [_p, _p, _i64, _p]),
+    "morna_get_stream": (C.c_int, [_p, _p]),
     "morna_get_n_items": (_i64, [_p]),
     "morna_get_item_vector": (C.c_int, [_p, _i32, _p]),
     "morna_get_item_vectors": (C.c_int, [_p, _p, _i64, _p]),

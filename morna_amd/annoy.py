@@ -69,6 +69,18 @@ class AnnoyIndex(object):
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         check(lib().morna_get_item_vectors(self._h, ptr(ids), len(ids), C.c_void_p(int(out_ptr))))
 
+    def get_item_vectors_dev(self, ids, out_ptr):
+        """Rows of `ids` written to out_ptr ([len(ids), f] fp32, this device's memory) in the order of the handle's
+        stream: no host wait."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        check(lib().morna_get_item_vectors_dev(self._h, ptr(ids), len(ids), C.c_void_p(int(out_ptr))))
+
+    def stream_ptr(self):
+        """The handle's HIP stream (hipStream_t as an integer), e.g. for torch.cuda.ExternalStream."""
+        out = C.c_void_p()
+        check(lib().morna_get_stream(self._h, C.byref(out)))
+        return int(out.value or 0)
+
     def get_nns_by_vector_ptr(self, q_ptr, nq, n, search_k=-1):
         """get_nns_by_vector_batch for nq contiguous fp32 rows at a raw (host or device) address."""
         ids = np.empty((nq, n), np.int32)
@@ -80,7 +92,8 @@ class AnnoyIndex(object):
 
     def get_nns_by_vector_packed(self, q_ptr, nq, n, search_k, id_offset, packed_ptr):
         """Row-sharded search, device hand-over: answers to nq fp32 queries at q_ptr (host or device) written to
-        packed_ptr (this device's memory) as the [nq, 2n] int32 message of the top-k all-gather."""
+        packed_ptr (this device's memory) as the [nq, 2n] int32 message of the top-k all-gather.  Enqueued on the
+        handle's stream (stream_ptr()), not waited for."""
         check(lib().morna_get_nns_by_vector_packed(self._h, C.c_void_p(int(q_ptr)), int(nq), int(n), int(search_k),
                                                    int(id_offset), C.c_void_p(int(packed_ptr))))
 

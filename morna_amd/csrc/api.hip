@@ -346,9 +346,37 @@ int morna_get_item_vector(morna_index *h, int32_t id, float *out)
     return MORNA_OK;
 }
 
+static int get_item_vectors_impl(morna_index *h, const int32_t *ids, int64_t n, float *out, bool wait);
+
 int morna_get_item_vectors(morna_index *h, const int32_t *ids, int64_t n, float *out)
 {
     CHECK_H(h);
+    return get_item_vectors_impl(h, ids, n, out, true);
+}
+
+int morna_get_item_vectors_dev(morna_index *h, const int32_t *ids, int64_t n, float *out_dev)
+{
+    CHECK_H(h);
+    if (n > 0 && !out_dev) {
+        set_error("get_item_vectors_dev: null buffer");
+        return MORNA_E_INVALID;
+    }
+    return get_item_vectors_impl(h, ids, n, out_dev, false);
+}
+
+int morna_get_stream(morna_index *h, void **stream_out)
+{
+    CHECK_H(h);
+    if (!stream_out) {
+        set_error("get_stream: null pointer");
+        return MORNA_E_INVALID;
+    }
+    *stream_out = (void *)h->stream;
+    return MORNA_OK;
+}
+
+static int get_item_vectors_impl(morna_index *h, const int32_t *ids, int64_t n, float *out, bool wait)
+{
     HIP_TRY(hipSetDevice(h->device));
     MORNA_TRY(upload_host_rows(h));
     for (int64_t i = 0; i < n; i++)
@@ -357,17 +385,20 @@ int morna_get_item_vectors(morna_index *h, const int32_t *ids, int64_t n, float 
             return MORNA_E_RANGE;
         }
     if (n <= 0) return MORNA_OK;
-    // one gather launch into a packed [n][dim] staging image, then ONE copy to `out`
-    // (host or device memory): a memcpy per row costs microseconds of launch each
+    // one gather launch into a packed [n][dim] image -- `out` itself when it is device memory handed over in stream
+    // order, else a staging image and ONE copy to `out` (host or device memory): a memcpy per row costs microseconds
+    // of launch each
     const size_t idb = ((size_t)n * 4 + 255) / 256 * 256;
-    MORNA_TRY(h->ws.alloc(idb + (size_t)n * h->dim * 4));
+    MORNA_TRY(h->ws.alloc(idb + (wait ? (size_t)n * h->dim * 4 : 0)));
     int32_t *d_ids = (int32_t *)h->ws.p;
-    float *d_rows = (float *)(h->ws.p + idb);
+    float *d_rows = wait ? (float *)(h->ws.p + idb) : out;
     HIP_TRY(hipMemcpyAsync(d_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n), dim3(256), 0, h->stream, h->X.p, d_ids, h->dim, h->dpad, d_rows);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out, d_rows, (size_t)n * h->dim * 4, hipMemcpyDefault, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (wait) {
+        HIP_TRY(hipMemcpyAsync(out, d_rows, (size_t)n * h->dim * 4, hipMemcpyDefault, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
     return MORNA_OK;
 }
 

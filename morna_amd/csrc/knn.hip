@@ -631,9 +631,9 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
             memcpy(ids_out + q0 * k, h->host_out, (size_t)nb * k * 4);
             if (dist_out) memcpy(dist_out + q0 * k, h->host_out + s_ids, (size_t)nb * k * 4);
             if (count_out) memcpy(count_out + q0, h->host_out + 2 * s_ids, (size_t)nb * 4);
-        } else {
-            HIP_TRY(hipStreamSynchronize(h->stream));
         }
+        // (packed answers only: nothing to wait for -- the next batch, and whatever the caller orders on the handle's
+        // stream, run behind this one)
     }
     return MORNA_OK;
 }
@@ -696,10 +696,20 @@ int merge_topk_dev(morna_index *h, const int32_t *gathered_dev, int32_t world, i
     hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->stream, gathered_dev, world, nq, kk,
                        k, d_ids, d_dist, d_cnt);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(ids_out, d_ids, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
-    if (dist_out) HIP_TRY(hipMemcpyAsync(dist_out, d_dist, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
-    if (count_out) HIP_TRY(hipMemcpyAsync(count_out, d_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream));
+    // one copy of the result block into the handle's page-locked staging, then plain memcpys (as query_batch)
+    const size_t out_bytes = 2 * s_ids + s_cnt;
+    if (out_bytes > h->host_out_cap) {
+        if (h->host_out) (void)hipHostFree(h->host_out);
+        h->host_out = nullptr;
+        h->host_out_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&h->host_out, out_bytes * 2, hipHostMallocDefault));
+        h->host_out_cap = out_bytes * 2;
+    }
+    HIP_TRY(hipMemcpyAsync(h->host_out, d_ids, out_bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    memcpy(ids_out, h->host_out, (size_t)nq * k * 4);
+    if (dist_out) memcpy(dist_out, h->host_out + s_ids, (size_t)nq * k * 4);
+    if (count_out) memcpy(count_out, h->host_out + 2 * s_ids, (size_t)nq * 4);
     return MORNA_OK;
 }
 

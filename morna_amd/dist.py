@@ -9,6 +9,8 @@ over xGMI -- after which every rank holds the merged (distance, id)-ordered top 
 `torch.distributed` with backend "nccl" is RCCL on ROCm; "gloo" is used by the
 CPU tests with a stand-in local index.
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -115,16 +117,25 @@ class ShardedSearch(object):
         return (self.device.type == "cuda" and hasattr(self.index, "get_nns_by_vector_packed")
                 and self.n_total < 2 ** 31 and self.world <= 64)
 
-    def _search_gather_merge_dev(self, q_ptr, nq, k, search_k):
+    def _lib_stream(self):
+        """The shard's own HIP stream as a torch stream: the collectives are enqueued between the library's kernels in
+        stream order, so the host never waits between query rows, search, all-gather and merge."""
+        if getattr(self, "_ext_stream", None) is None:
+            self._ext_stream = torch.cuda.ExternalStream(self.index.stream_ptr(), device=self.device)
+        return self._ext_stream
+
+    def _search_gather_merge_dev(self, q_ptr, nq, k, search_k, keep=None):
         """The data path of SURVEY.md 8(e) without a host hop: per-shard top-k written to HBM as one [nq, 2k] int32
         message (global ids, distance bits), RCCL all-gather of Q*k*8 bytes per rank, merge kernel; only the merged
-        result crosses PCIe."""
-        packed = torch.empty((nq, 2 * k), dtype=torch.int32, device=self.device)
-        self.index.get_nns_by_vector_packed(q_ptr, nq, k, search_k, int(self.offsets[self.rank]), packed.data_ptr())
-        gathered = torch.empty((self.world, nq, 2 * k), dtype=torch.int32, device=self.device)
-        dist.all_gather_into_tensor(gathered, packed, group=self.group)
-        torch.cuda.current_stream().synchronize()                 # the library merges on its own stream
-        ids, d, cnt = self.index.merge_topk_packed(gathered.data_ptr(), self.world, nq, k, k)
+        result crosses PCIe.  Everything is ordered on the library's stream; the one host wait is for the merged result.
+        keep: tensors the enqueued work reads (kept alive until it has run)."""
+        with torch.cuda.stream(self._lib_stream()):
+            packed = torch.empty((nq, 2 * k), dtype=torch.int32, device=self.device)
+            self.index.get_nns_by_vector_packed(q_ptr, nq, k, search_k, int(self.offsets[self.rank]), packed.data_ptr())
+            gathered = torch.empty((self.world, nq, 2 * k), dtype=torch.int32, device=self.device)
+            dist.all_gather_into_tensor(gathered, packed, group=self.group)
+            ids, d, cnt = self.index.merge_topk_packed(gathered.data_ptr(), self.world, nq, k, k)   # waits for the stream
+        del keep
         return ids.astype(np.int64), d, cnt
 
     def get_nns_by_vector(self, Q, k, search_k=-1):
@@ -165,15 +176,22 @@ class ShardedSearch(object):
         f = self.index.f
         if self.device.type == "cuda" and hasattr(self.index, "get_nns_by_vector_ptr"):
             # RCCL path: the query rows go HBM -> xGMI -> HBM, never through the host
-            mine = torch.zeros((n_max, f), dtype=torch.float32, device=self.device)
-            if len(items):
-                self.index.get_item_vectors_into(items, mine.data_ptr())       # synchronises the library's stream
-            outs = [torch.empty_like(mine) for _ in range(self.world)]
-            dist.all_gather(outs, mine, group=self.group)                       # query vectors: nq * D * 4 bytes, once
-            Q = torch.cat([outs[g][:n_each[g]] for g in range(self.world)], dim=0).contiguous()
-            torch.cuda.current_stream().synchronize()                          # the library reads Q on its own stream
-            if self._device_path() and k <= 255:
-                return self._search_gather_merge_dev(Q.data_ptr(), Q.shape[0], k, search_k)
+            dev_path = self._device_path() and k <= 255 and hasattr(self.index, "get_item_vectors_dev")
+            with torch.cuda.stream(self._lib_stream()) if dev_path else contextlib.nullcontext():
+                even = all(n == n_max for n in n_each)
+                mine = (torch.empty if even else torch.zeros)((n_max, f), dtype=torch.float32, device=self.device)
+                if len(items):
+                    if dev_path:
+                        self.index.get_item_vectors_dev(items, mine.data_ptr())    # in stream order, no host wait
+                    else:
+                        self.index.get_item_vectors_into(items, mine.data_ptr())   # synchronises the library's stream
+                allq = torch.empty((self.world, n_max, f), dtype=torch.float32, device=self.device)
+                dist.all_gather_into_tensor(allq, mine, group=self.group)          # query vectors: nq * D * 4 bytes, once
+                Q = allq.view(-1, f) if even else \
+                    torch.cat([allq[g, :n_each[g]] for g in range(self.world)], dim=0).contiguous()
+            if dev_path:
+                return self._search_gather_merge_dev(Q.data_ptr(), Q.shape[0], k, search_k, keep=(mine, allq, Q))
+            torch.cuda.current_stream().synchronize()                              # the library reads Q on its own stream
             ids, d, cnt = self.index.get_nns_by_vector_ptr(Q.data_ptr(), Q.shape[0], k, search_k)
             return self._gather_merge(ids, d, k)
         mine = np.zeros((n_max, f), np.float32)

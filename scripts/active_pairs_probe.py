@@ -62,7 +62,7 @@ def main():
     out = {"N": int(N), "T": int(T), "tile": a.tile, "levels": []}
     # node_of[L][t][row]: the split node of level L the row is in (or -1)
     n_tiles = (N + a.tile - 1) // a.tile
-    prev_keys = None
+    fixed = {}
     for L in range(n_levels):
         nodes = np.nonzero((level == L) & (kind == 0))[0]
         if len(nodes) == 0:
@@ -84,6 +84,17 @@ def main():
             for t in range(6):
                 k6 = k6 * 64 + (node_of[t] + 1)
             orders["tree0..5"] = np.argsort(k6, kind="stable")
+        for name in list(orders):
+            if name != "natural":
+                fixed["L%d:%s" % (L, name)] = orders[name]
+        for name, o in fixed.items():
+            if not name.startswith("L%d:" % L):
+                orders[name] = o
+        if T >= 12 and L >= 1:
+            k12 = np.zeros(N, np.int64)
+            for t in range(12):
+                k12 = k12 * 32 + (node_of[t] + 1)
+            fixed["L%d:tree0..11" % L] = np.argsort(k12, kind="stable")
         lvl = {"level": L, "split_nodes": int(S), "dense_blocks_256": int(n_tiles * ((S + 255) // 256)), "orders": {}}
         for name, order in orders.items():
             rank = np.empty(N, np.int64)

@@ -138,3 +138,32 @@ def test_packed_device_exchange_equals_host_merge():
     assert ids5.tolist() == ids[:, :5].tolist() and (cnt5 == 5).all()
     with pytest.raises(ValueError):
         shards[0].merge_topk_packed(gathered.data_ptr(), 65, len(Q), k, 5)
+
+
+def test_stream_ordered_hand_over():
+    """morna_get_stream + morna_get_item_vectors_dev + the packed search without a host wait in between: work a caller
+    orders on the handle's stream (here torch copies under torch.cuda.ExternalStream) sees what the library enqueued."""
+    import torch
+    from morna_amd.annoy import AnnoyIndex
+    X = _rows()
+    a = AnnoyIndex(F)
+    a.add_items(X)
+    a.build(T)
+    dev = torch.device("cuda", 0)
+    items = np.array([5, 4999, 0, 5, 1234], np.int32)
+    k = 10
+    ext = torch.cuda.ExternalStream(a.stream_ptr(), device=dev)
+    with torch.cuda.stream(ext):
+        rows = torch.empty((len(items), F), dtype=torch.float32, device=dev)
+        a.get_item_vectors_dev(items, rows.data_ptr())
+        packed = torch.empty((len(items), 2 * k), dtype=torch.int32, device=dev)
+        a.get_nns_by_vector_packed(rows.data_ptr(), len(items), k, -1, 100, packed.data_ptr())
+        msg = packed.clone()            # a torch kernel behind the library's, same stream
+    a.synchronize()
+    assert rows.cpu().numpy().tobytes() == X[items].tobytes()
+    ids, d, cnt = a.get_nns_by_item_batch(items, k, -1)
+    got = msg.cpu().numpy()
+    assert got[:, :k].tolist() == (ids + 100).tolist()
+    assert got[:, k:].view(np.float32).tobytes() == d.tobytes()
+    with pytest.raises(IndexError):
+        a.get_item_vectors_dev(np.array([5000], np.int32), rows.data_ptr())
