@@ -258,8 +258,8 @@ __global__ void flags_to_serial_kernel(uint8_t *__restrict__ flag, int64_t J)
 // One piece of a line (up to NU * 64 entries from entry c0): positions of its items, ascending test, tile starts.
 // Branch-free over the NU register sets -- every load of a phase is in flight before the first result is used; entries
 // past the end of the line re-read its first entry and are masked afterwards.
-template <int TILE_SHIFT, int NU>
-__device__ inline void line_prep_piece(const int32_t *__restrict__ ids, const int32_t *__restrict__ rank, int32_t n_items, int64_t b,
+template <int TILE_SHIFT, int NU, typename RankT>
+__device__ inline void line_prep_piece(const int32_t *__restrict__ ids, const RankT *__restrict__ rank, int32_t n_items, int64_t b,
                                        int32_t len, int32_t c0, int32_t n_tiles, int32_t *__restrict__ off, int32_t *__restrict__ pid,
                                        int lane, bool &asc, int32_t &prev_last)
 {
@@ -274,7 +274,7 @@ __device__ inline void line_prep_piece(const int32_t *__restrict__ ids, const in
     for (int u = 0; u < NU; u++) {
         const bool ok = (uint32_t)p[u] < (uint32_t)n_items;
         bad |= !ok;
-        const int32_t r = rank[ok ? p[u] : 0];
+        const int32_t r = (int32_t)rank[ok ? p[u] : 0];
         p[u] = ok ? r : -1;
     }
     if (__any(bad)) asc = false;   // the line takes the scanned path, where a position of -1 falls into no tile
@@ -308,15 +308,13 @@ __device__ inline void line_prep_piece(const int32_t *__restrict__ ids, const in
     prev_last = __shfl(v, last_e % WAVE, WAVE);
 }
 
-template <int TILE_SHIFT>
-__global__ __launch_bounds__(256) void line_prep_kernel(const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ ids,
-                                                        const int32_t *__restrict__ rank, int32_t n_items, int64_t J, int32_t n_tiles,
-                                                        int32_t *__restrict__ tile_off /* [J][n_tiles + 1] */,
-                                                        int32_t *__restrict__ pid /* [nnz] position of each entry's item */,
-                                                        uint8_t *__restrict__ flag)
+// the lines j = wave, wave + n_waves, ... of one wave
+template <int TILE_SHIFT, typename RankT>
+__device__ inline void line_prep_lines(const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ ids,
+                                       const RankT *__restrict__ rank, int32_t n_items, int64_t J, int32_t n_tiles,
+                                       int32_t *__restrict__ tile_off, int32_t *__restrict__ pid, uint8_t *__restrict__ flag,
+                                       int64_t wave, int64_t n_waves, int lane)
 {
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) / WAVE, n_waves = (int64_t)gridDim.x * (256 / WAVE);
     for (int64_t j = wave; j < J; j += n_waves) {
         const int64_t b = row_ptr[j];
         const int32_t len = (int32_t)(row_ptr[j + 1] - b);
@@ -346,6 +344,37 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const int64_t *__restric
     }
 }
 
+template <int TILE_SHIFT>
+__global__ __launch_bounds__(256) void line_prep_kernel(const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ ids,
+                                                        const int32_t *__restrict__ rank, int32_t n_items, int64_t J, int32_t n_tiles,
+                                                        int32_t *__restrict__ tile_off /* [J][n_tiles + 1] */,
+                                                        int32_t *__restrict__ pid /* [nnz] position of each entry's item */,
+                                                        uint8_t *__restrict__ flag)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) / WAVE, n_waves = (int64_t)gridDim.x * (256 / WAVE);
+    line_prep_lines<TILE_SHIFT>(row_ptr, ids, rank, n_items, J, n_tiles, tile_off, pid, flag, wave, n_waves, lane);
+}
+
+// The same with the item -> position table in LDS as 16-bit entries (up to 65536 items: 128 KB), one workgroup per CU.
+// The look-up rank[id] is a gather of 64 scattered words per instruction: served by the L2 it is the kernel's bound
+// (one cache line per lane), served by LDS it costs a few clocks.
+#define LPL_THREADS 768
+template <int TILE_SHIFT>
+__global__ __launch_bounds__(LPL_THREADS) void line_prep_lds_kernel(const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ ids,
+                                                                    const int32_t *__restrict__ rank, int32_t n_items, int64_t J,
+                                                                    int32_t n_tiles, int32_t *__restrict__ tile_off,
+                                                                    int32_t *__restrict__ pid, uint8_t *__restrict__ flag)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t *tab = (uint16_t *)smem;
+    for (int i = threadIdx.x; i < n_items; i += LPL_THREADS) tab[i] = (uint16_t)rank[i];
+    __syncthreads();
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * LPL_THREADS + threadIdx.x) / WAVE, n_waves = (int64_t)gridDim.x * (LPL_THREADS / WAVE);
+    line_prep_lines<TILE_SHIFT>(row_ptr, ids, tab, n_items, J, n_tiles, tile_off, pid, flag, wave, n_waves, lane);
+}
+
 // One workgroup of four waves per (column, tile of TILE consecutive positions of the item order): the tile's fp64
 // accumulators live in LDS, the column's lines are walked in file order, and of each line only the piece that falls
 // into the tile is read -- a thread has at most one entry of a piece (pieces longer than the workgroup take more rounds),
@@ -362,7 +391,8 @@ __global__ __launch_bounds__(AW_THREADS) void accumulate_piece_kernel(
     int32_t n_tiles, int32_t n_cols, const int32_t *__restrict__ col_off, const int32_t *__restrict__ col_lines,
     const double *__restrict__ sidf, const uint8_t *__restrict__ flags, const int64_t *__restrict__ row_ptr,
     const int32_t *__restrict__ tile_off, const int32_t *__restrict__ pid, const int32_t *__restrict__ cov,
-    int64_t n_items, float *__restrict__ colacc /* [D][n_items], by position in the order */)
+    int64_t n_items, float *__restrict__ colacc /* [D][n_items], by position in the order */,
+    int32_t min_lines /* columns with fewer lines are left to accumulate_wave_kernel */)
 {
     __shared__ double acc[TILE];
     __shared__ int64_t s_b[AW_LINES];
@@ -372,8 +402,9 @@ __global__ __launch_bounds__(AW_THREADS) void accumulate_piece_kernel(
     const int c = (int)(blockIdx.x / n_tiles), t = (int)(blockIdx.x % n_tiles);   // consecutive tiles of a column: neighbours
     const int32_t p_lo = t * TILE;
     const uint32_t span = (uint32_t)((int64_t)p_lo + TILE < n_items ? TILE : n_items - p_lo);
-    for (int i = tid; i < TILE; i += AW_THREADS) acc[i] = 0.0;
     const int nl = col_off[c + 1] - col_off[c];
+    if (nl < min_lines) return;
+    for (int i = tid; i < TILE; i += AW_THREADS) acc[i] = 0.0;
     const int32_t *lines = col_lines + col_off[c];
     const int tstride = n_tiles + 1;
 
@@ -399,14 +430,22 @@ __global__ __launch_bounds__(AW_THREADS) void accumulate_piece_kernel(
         __syncthreads();
         // every load unconditional (a thread with no entry in a piece re-reads entry 0 of the arrays; the line loop knows
         // which threads count): a select on the loaded value would make each load wait for itself
+        // ... but a WAVE none of whose threads has an entry in a piece (at C3 a piece is ~110 entries: the third and fourth
+        // wave, and every wave for the slots past the column's last line) skips the pair of loads: a scalar branch
         int32_t P[AW_LINES], C[AW_LINES];
+        const int wbase = tid & ~(WAVE - 1);
 #pragma unroll
         for (int i = 0; i < AW_LINES; i++) {
             const int ii = i < nlc ? i : 0;
-            const int32_t e = s_lo[ii] + tid;
-            const int64_t at = e < s_hi[ii] ? s_b[ii] + e : 0;
-            P[i] = pid[at];
-            C[i] = cov[at];
+            const int32_t lo_i = __builtin_amdgcn_readfirstlane(s_lo[ii]), hi_i = __builtin_amdgcn_readfirstlane(s_hi[ii]);
+            P[i] = 0;
+            C[i] = 0;
+            if (i < nlc && lo_i + wbase < hi_i) {
+                const int32_t e = lo_i + tid;
+                const int64_t at = e < hi_i ? s_b[ii] + e : 0;
+                P[i] = pid[at];
+                C[i] = cov[at];
+            }
         }
 #pragma unroll
         for (int i = 0; i < AW_LINES; i++) {
@@ -822,7 +861,7 @@ int build_features(morna_index *h, int64_t n_items)
     ScratchRef<int32_t> bucket_aux(h->scratch[7]);   // [J] rank of a line in its chunk, then [n_chunks][D] chunk counts / bases
     // with an item order whose length matches: the wave-per-tile form (each entry of the nnz stream read once)
     static const bool wave_on = !(getenv("MORNA_FEATURES_WAVE") && atoi(getenv("MORNA_FEATURES_WAVE")) == 0);
-    const bool by_order = wave_on && h->order_n == n_items && J > 0;
+    const bool by_order = wave_on && h->order_n == n_items && J > 0 && h->nnz > 0;   // (the kernels read entry 0 as a dummy)
     constexpr int AW_TILE_SHIFT = 12, AW_TILE = 1 << AW_TILE_SHIFT;   // 4096 positions: 0.61 ms at C3 (2048: 0.76, 8192: 0.83)
     const int32_t aw_tiles = (int32_t)((n_items + AW_TILE - 1) / AW_TILE);
     ScratchRef<int32_t> tile_off(h->scratch[24]);        // [J][aw_tiles + 1] where each tile's piece of a line begins
@@ -858,9 +897,20 @@ int build_features(morna_index *h, int64_t n_items)
             if (by_order) {
                 // ascending check + tile extents of every line; the flag kernels below then look at the lines that do
                 // not ascend only (none, for a file whose lines are sorted and an order that says so)
-                const int lp_blocks = (int)std::max<int64_t>(1, std::min<int64_t>((J + 3) / 4, (int64_t)h->n_cus * 8));
-                hipLaunchKernelGGL(line_prep_kernel<AW_TILE_SHIFT>, dim3(lp_blocks), dim3(256), 0, h->stream2, h->s_row_ptr.p,
-                                   h->s_ids.p, h->item_rank.p, (int32_t)n_items, J, aw_tiles, tile_off.p, pid.p, flags.p);
+                static const bool lds_rank = !(getenv("MORNA_PREP_LDS") && atoi(getenv("MORNA_PREP_LDS")) == 0);
+                if (lds_rank && n_items <= 65536) {
+                    const size_t lds = ((size_t)n_items * 2 + 15) / 16 * 16;
+                    HIP_TRY(hipFuncSetAttribute((const void *)line_prep_lds_kernel<AW_TILE_SHIFT>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    const int lp_blocks = (int)std::max<int64_t>(1, std::min<int64_t>((J + 11) / 12, (int64_t)h->n_cus));
+                    hipLaunchKernelGGL(line_prep_lds_kernel<AW_TILE_SHIFT>, dim3(lp_blocks), dim3(LPL_THREADS), lds, h->stream2,
+                                       h->s_row_ptr.p, h->s_ids.p, h->item_rank.p, (int32_t)n_items, J, aw_tiles, tile_off.p, pid.p,
+                                       flags.p);
+                } else {
+                    const int lp_blocks = (int)std::max<int64_t>(1, std::min<int64_t>((J + 3) / 4, (int64_t)h->n_cus * 8));
+                    hipLaunchKernelGGL(line_prep_kernel<AW_TILE_SHIFT>, dim3(lp_blocks), dim3(256), 0, h->stream2, h->s_row_ptr.p,
+                                       h->s_ids.p, h->item_rank.p, (int32_t)n_items, J, aw_tiles, tile_off.p, pid.p, flags.p);
+                }
             }
             if (n_words <= LFW_MAX_WORDS) {
                 const size_t lds = (size_t)LFW_WAVES * (size_t)n_words * 4;
@@ -899,7 +949,7 @@ int build_features(morna_index *h, int64_t n_items)
         if (by_order) {
             hipLaunchKernelGGL(accumulate_piece_kernel<AW_TILE>, dim3((unsigned)D * (unsigned)aw_tiles), dim3(AW_THREADS), 0, h->stream, aw_tiles,
                                (int32_t)D, col_off.p, col_lines.p, sidf.p, flags.p, h->s_row_ptr.p, tile_off.p, pid.p,
-                               h->s_cov.p, n_items, colacc.p);
+                               h->s_cov.p, n_items, colacc.p, 0);
         } else {
             const unsigned tiles = (unsigned)((n_items + ACC_TILE - 1) / ACC_TILE);
             // workgroup b runs on XCD b % 8: the sample tiles of one column are dealt to ONE XCD, back to back, so the
