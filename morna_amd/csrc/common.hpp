@@ -144,6 +144,7 @@ struct morna_index {
     bool norms_valid = false;
     bool unsettled = false;      // build_features() returned without waiting for its kernels: blocking copies must settle() first
     bool half_valid = false;     // scratch[19] / [20] hold the fp16 image of X, its norms and scales (splitmm.hip)
+    bool ord_valid = false;      // the build under way has ordered its rows for the split contraction (splitmm.hip, scratch[29..33])
 
     // staged junction lines (CSR by line, file order)
     int64_t J = 0, nnz = 0, key_bytes_n = 0;
@@ -174,7 +175,7 @@ struct morna_index {
     morna::DevBuf<uint8_t> ws;
     // build scratch kept between calls (feature and forest builds reuse it instead of
     // hipMalloc / hipFree on every call); slots are named in features.hip / forest.hip
-    morna::DevBuf<uint8_t> scratch[29];
+    morna::DevBuf<uint8_t> scratch[34];
     // [0] rows read by query kernels (hyperplane dots + candidates + 1 per query)
     morna::DevBuf<unsigned long long> d_stat;
 
@@ -239,6 +240,8 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed);
 int split_mm_prepare_rows(morna_index *h, hipStream_t stream);   // stream: the handle's main or side stream
 int split_mm_convert_rows(morna_index *h, const float *src, int64_t rows, _Float16 *dst, float *norm, float *err,
                           float *inv_scale, hipStream_t stream);
+int split_mm_order_rows(morna_index *h, const uint8_t *side, const int32_t *perm, int32_t n_trees, hipStream_t stream,
+                        const int32_t **rank_out, int32_t **inv_out);
 int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, const float *hp_level,
                    const int32_t *perm, const int32_t *inv, uint32_t seed, uint8_t *side, int32_t *ones);
 // packed_dev (device memory, or null): [nq][2k] int32 message of the row-sharded search -- ids + id_offset, distance bits

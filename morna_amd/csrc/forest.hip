@@ -881,7 +881,8 @@ template <int PT>
 __global__ __launch_bounds__(PT) void partition_kernel(const SplitTask *__restrict__ tasks, int64_t n_items,
                                                        const uint8_t *__restrict__ side,
                                                        const int32_t *__restrict__ ones, int32_t *__restrict__ perm,
-                                                       int32_t *__restrict__ tmp, int32_t *__restrict__ inv)
+                                                       int32_t *__restrict__ tmp, int32_t *__restrict__ inv,
+                                                       const int32_t *__restrict__ rank /* inv is indexed by rank[item] (or null: by item) */)
 {
     __shared__ int s_w1[PT / WAVE];
     const SplitTask t = tasks[blockIdx.x];
@@ -926,7 +927,7 @@ __global__ __launch_bounds__(PT) void partition_kernel(const SplitTask *__restri
                 const int dst = sd[u] ? (n0 + run1 + r1) : (run0 + (rv - r1));
                 const int32_t item = perm[base + pb + u];
                 tmp[base + dst] = item;
-                if (inv) inv[(int64_t)t.tree * n_items + item] = t.start + dst;
+                if (inv) inv[(int64_t)t.tree * n_items + (rank ? rank[item] : item)] = t.start + dst;
                 r1 += sd[u];
                 rv += 1;
             }
@@ -1006,9 +1007,12 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
     ScratchRef<int32_t> row_task(h->scratch[16]), row_pos(h->scratch[17]), d_tree_first(h->scratch[18]);
     // matrix-core split: position of every item in every tree's permutation, kept current by partition_kernel
     static const bool mm_on = !(getenv("MORNA_SPLIT_MM") && atoi(getenv("MORNA_SPLIT_MM")) == 0);
+    static const bool order_on = !(getenv("MORNA_SPLIT_ORDER") && atoi(getenv("MORNA_SPLIT_ORDER")) == 0);
     ScratchRef<int32_t> inv(h->scratch[26]);
     if (mm_on) MORNA_TRY(inv.alloc((size_t)n_trees * N));
-    int32_t *const inv_p = mm_on ? inv.p : nullptr;
+    int32_t *inv_p = mm_on ? inv.p : nullptr;   // by item; by row once the rows have been ordered (rank_p)
+    const int32_t *rank_p = nullptr;
+    h->ord_valid = false;
     std::vector<int32_t> tree_first;
     {
         const int64_t total = (int64_t)n_trees * N;
@@ -1115,10 +1119,10 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 ScopedTimer tm(h, MORNA_T_PARTITION, 0);
                 if (level_rows >= (int64_t)A * 2048)
                     hipLaunchKernelGGL(partition_kernel<1024>, dim3((unsigned)A), dim3(1024), 0, h->stream, d_tasks.p, N, side.p,
-                                       d_ones.p, h->perm.p, tmp.p, inv_p);
+                                       d_ones.p, h->perm.p, tmp.p, inv_p, rank_p);
                 else
                     hipLaunchKernelGGL(partition_kernel<256>, dim3((unsigned)A), dim3(256), 0, h->stream, d_tasks.p, N, side.p,
-                                       d_ones.p, h->perm.p, tmp.p, inv_p);
+                                       d_ones.p, h->perm.p, tmp.p, inv_p, rank_p);
             }
             if (hipGetLastError() != hipSuccess) {
                 set_error("forest build: partition launch failed");
@@ -1187,6 +1191,15 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 if ((rc = split_mm_prepare_rows(h, h->stream2))) { cleanup(); return rc; }
                 F_TRY(hipEventRecord(h->ev_join, h->stream2));
                 side_work = true;
+            } else if (use_mm && order_on && level == 1 && !h->ord_valid && N >= 8192 && n_trees >= 2) {
+                // second level: the rows of the contraction are put in an order in which neighbours are alike (the sides of
+                // the root splits say which are), on the side stream under this level's two_means; from here on `inv` is
+                // kept by row (splitmm.hip, split_mm_order_rows)
+                F_TRY(hipEventRecord(h->ev_fork, h->stream));
+                F_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+                if ((rc = split_mm_order_rows(h, side.p, h->perm.p, n_trees, h->stream2, &rank_p, &inv_p))) { cleanup(); return rc; }
+                F_TRY(hipEventRecord(h->ev_join, h->stream2));
+                side_work = true;
             } else if (use_rw && !use_mm) {
                 // row-window form (MORNA_SPLIT_MM=0): row -> (task, position) per tree on the side stream
                 if ((rc = row_task.alloc((size_t)n_trees * N)) || (rc = row_pos.alloc((size_t)n_trees * N)) ||
@@ -1252,7 +1265,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             if (side_work) F_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
             if (use_mm) {
                 ScopedTimer tm(h, MORNA_T_SPLIT, 4 * (int64_t)D * (rows + A));
-                if ((rc = split_mm_level(h, d_tasks.p, A, hp_level, h->perm.p, inv.p, seed, side.p, d_ones.p))) {
+                if ((rc = split_mm_level(h, d_tasks.p, A, hp_level, h->perm.p, inv_p, seed, side.p, d_ones.p))) {
                     cleanup();
                     return rc;
                 }

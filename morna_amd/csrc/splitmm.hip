@@ -100,7 +100,8 @@ template <bool BIG>
 __global__ __launch_bounds__(BIG ? 1024 : 512) void split_mm_kernel(
     const _Float16 *__restrict__ X16, const float *__restrict__ xn, const float *__restrict__ xe, int64_t n_items, int32_t dpad,
     const _Float16 *__restrict__ H16, const float *__restrict__ hn, const float *__restrict__ he, int32_t n_tasks,
-    const SplitTask *__restrict__ tasks, const int32_t *__restrict__ inv /* [tree][item] position in the tree's permutation */,
+    const SplitTask *__restrict__ tasks, const int32_t *__restrict__ inv /* [tree][row] position in the tree's permutation */,
+    const int32_t *__restrict__ item_at /* the item each ROW of the contraction stands for (split_mm_order_rows), or null: row = item */,
     float eps, uint8_t *__restrict__ side, int32_t *__restrict__ ones, unsigned int *__restrict__ amb_count,
     int2 *__restrict__ amb, unsigned int amb_cap,
     const int32_t *__restrict__ col_list /* [row tiles][n_tasks] the tasks each row tile needs, ascending; null: all of them */,
@@ -170,7 +171,10 @@ __global__ __launch_bounds__(BIG ? 1024 : 512) void split_mm_kernel(
     // past the end repeat the last one: their products are never looked up
     constexpr int NB = BIG ? 2 : 1;
     f32x16 acc[NB][2];
-    auto b_row = [&](int rt) { return r0 + rt < n_items ? r0 + rt : n_items - 1; };
+    auto b_row = [&](int rt) {
+        const int64_t r = r0 + rt < n_items ? r0 + rt : n_items - 1;
+        return item_at ? (int64_t)item_at[r] : r;   // (a lane asks once: the delivery addresses are kept in registers)
+    };
     auto a_row = [&](int rt) { return (int64_t)s_task[rt]; };
     if constexpr (BIG) mm16_tile_256x256<64, 2>(X16, H16, dpad, smem, b_row, a_row, acc);   // (4 stages of 32 halfs, three deliveries in flight: 0.62 / 0.73 ms against 0.57 / 0.66 at C3)
     else mm16_tile<128, 64, 2>(X16, H16, dpad, smem, b_row, a_row, acc);
@@ -180,7 +184,8 @@ __global__ __launch_bounds__(BIG ? 1024 : 512) void split_mm_kernel(
     const int64_t row = r0 + (tid & (ROWS - 1));
     const bool row_ok = row < n_items;
     // bound of a pair = (EACC |y| + |d|) |g| + (|y| + |d|) |f|, 0.5 % of slack for its own roundings
-    const float xn_r = xn[row_ok ? row : 0], xe_r = xe[row_ok ? row : 0];
+    const int64_t item = row_ok ? (item_at ? (int64_t)item_at[row] : row) : 0;
+    const float xn_r = xn[item], xe_r = xe[item];
     const float xa = (eps * xn_r + xe_r) * 1.005f, xb = (xn_r + xe_r) * 1.005f;
 #pragma unroll
     for (int half = 0; half < COLS / 128; half++) {
@@ -297,14 +302,22 @@ __global__ __launch_bounds__(BIG ? 1024 : 512) void split_mm_kernel(
 // the node's slice of the permutation; the byte stores need no atomics.
 __global__ __launch_bounds__(256) void split_active_mark_kernel(const SplitTask *__restrict__ tasks,
                                                                 const int32_t *__restrict__ perm, int64_t n_items,
+                                                                const int32_t *__restrict__ rank /* row of each item, or null: its id */,
                                                                 int tile_shift, int32_t n_tasks, uint8_t *__restrict__ active)
 {
     const SplitTask t = tasks[blockIdx.x];
     const int32_t *items = perm + (int64_t)t.tree * n_items + t.start;
-    // a node's items ascend (stable partitions of the identity): only the first item of a run in the same tile stores
-    for (int i = threadIdx.x; i < t.count; i += 256) {
-        const int tile = items[i] >> tile_shift;
-        if (i == 0 || (items[i - 1] >> tile_shift) != tile) active[(int64_t)tile * n_tasks + blockIdx.x] = 1;
+    // neighbours in a node's list are often in the same tile (ids ascend along the list; ordered rows keep much of that):
+    // only the first item of a run in the same tile stores.  The previous item's tile comes from the lane below.
+    const int lane = threadIdx.x & (WAVE - 1);
+    for (int i0 = 0; i0 < t.count; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        const bool valid = i < t.count;
+        const int32_t it = valid ? items[i] : 0;
+        const int tile = (rank ? rank[it] : it) >> tile_shift;
+        int prev = __shfl_up(tile, 1, WAVE);
+        if (lane == 0) prev = -1;   // (the first lane of a wave always stores: cheaper than fetching its neighbour's row)
+        if (valid && prev != tile) active[(int64_t)tile * n_tasks + blockIdx.x] = 1;
     }
 }
 
@@ -362,17 +375,18 @@ __global__ __launch_bounds__(256) void split_amb_kernel(const float *__restrict_
                                                         const float *__restrict__ hp,
                                                         const unsigned int *__restrict__ amb_count,
                                                         const int2 *__restrict__ amb, unsigned int amb_cap,
-                                                        uint8_t *__restrict__ side, int32_t *__restrict__ ones)
+                                                        uint8_t *__restrict__ side, int32_t *__restrict__ ones,
+                                                        const int32_t *__restrict__ item_at /* item of each row of the contraction, or null: the row */)
 {
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
     const int nvec = dpad / 4;
     unsigned int n = *amb_count;
     if (n > amb_cap) n = amb_cap;   // cannot happen: the list holds one entry per (row, tree) at most
     for (unsigned int i = blockIdx.x * (256 / WAVE) + w; i < n; i += gridDim.x * (256 / WAVE)) {
-        const int2 pr = amb[i];
+        const int2 pr = amb[i];   // (row of the contraction -- `inv` is indexed by it --, task)
         const SplitTask t = tasks[pr.y];
-        const float d = wave_dot((const float4 *)(X + (int64_t)pr.x * dpad), (const float4 *)(hp + (int64_t)t.slot * dpad),
-                                 nvec, lane);
+        const int64_t item = item_at ? item_at[pr.x] : pr.x;
+        const float d = wave_dot((const float4 *)(X + item * dpad), (const float4 *)(hp + (int64_t)t.slot * dpad), nvec, lane);
         if (lane == 0) {
             const int pos = inv[(int64_t)t.tree * n_items + pr.x] - t.start;
             const uint32_t nseed = node_seed(seed, (uint32_t)t.tree, (uint32_t)t.level, (uint32_t)t.start, (uint32_t)t.attempt);
@@ -382,6 +396,144 @@ __global__ __launch_bounds__(256) void split_amb_kernel(const float *__restrict_
             if (s) atomicAdd(&ones[pr.y], 1);
         }
     }
+}
+
+// ---- an order of the rows for the deep levels ---------------------------------------------------------------------
+// The lists above are short when the rows of a tile are alike: in every tree they then sit in the same few nodes.  After the
+// root level the forest itself says which rows are alike: key(item) = the side the item took at the root of trees 0 .. 11,
+// one bit per tree.  Rows sorted by that key (ties by id: a counting sort with a stable in-block rank, deterministic) make
+// the ROWS of the contraction from the second level on; `rank` (row of an item) and `item_at` (item of a row) translate.
+// C3, blocks of 256 rows x 256 tasks the lists leave at the levels with 800 / 1600 / 1936 split nodes: 494 / 650 / 546,
+// against 640 / 971 / 964 with the rows in id order and 784 / 1372 / 1568 without lists (scripts/active_pairs_probe.py).
+// The order changes which products are computed, never a side: tests compare forests with MORNA_SPLIT_ORDER=0.
+#define ORD_BITS 12
+#define ORD_BINS (1 << ORD_BITS)
+#define ORD_BLOCK 256
+
+__global__ __launch_bounds__(256) void order_key_kernel(const uint8_t *__restrict__ side /* [tree][position = item at the root] */,
+                                                        int64_t n_items, int n_bits, uint16_t *__restrict__ key)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_items) return;
+    uint32_t k = 0;
+    for (int t = 0; t < n_bits; t++) k = (k << 1) | (side[(int64_t)t * n_items + i] ? 1u : 0u);
+    key[i] = (uint16_t)k;
+}
+
+__global__ __launch_bounds__(ORD_BLOCK) void order_hist_kernel(const uint16_t *__restrict__ key, int64_t n_items, int32_t n_blocks,
+                                                               int32_t *__restrict__ cnt /* [ORD_BINS][blocks] */)
+{
+    __shared__ int s_cnt[ORD_BINS];
+    for (int k = threadIdx.x; k < ORD_BINS; k += ORD_BLOCK) s_cnt[k] = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * ORD_BLOCK + threadIdx.x;
+    if (i < n_items) atomicAdd(&s_cnt[key[i]], 1);
+    __syncthreads();
+    for (int k = threadIdx.x; k < ORD_BINS; k += ORD_BLOCK) cnt[(int64_t)k * n_blocks + blockIdx.x] = s_cnt[k];
+}
+
+// one wave per key: cnt[k][b] <- items with key k in the blocks before b; total[k]
+__global__ __launch_bounds__(256) void order_scan_bins_kernel(int32_t *__restrict__ cnt, int32_t n_blocks, int32_t *__restrict__ total)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int k = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
+    int32_t *row = cnt + (int64_t)k * n_blocks;
+    int run = 0;
+    for (int b0 = 0; b0 < n_blocks; b0 += WAVE) {
+        const int v = b0 + lane < n_blocks ? row[b0 + lane] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const int u = __shfl_up(incl, o, WAVE);
+            if (lane >= o) incl += u;
+        }
+        if (b0 + lane < n_blocks) row[b0 + lane] = run + incl - v;
+        run += __shfl(incl, WAVE - 1, WAVE);
+    }
+    if (lane == 0) total[k] = run;
+}
+
+// total[k] <- items with a smaller key (one workgroup, four keys per thread)
+__global__ __launch_bounds__(1024) void order_scan_keys_kernel(int32_t *__restrict__ total)
+{
+    static_assert(ORD_BINS == 4096, "four bins per thread");
+    __shared__ int s_part[1024];
+    int t[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) t[u] = total[threadIdx.x * 4 + u];
+    const int mine = t[0] + t[1] + t[2] + t[3];
+    s_part[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int base = s_part[threadIdx.x] - mine;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        total[threadIdx.x * 4 + u] = base;
+        base += t[u];
+    }
+}
+
+__global__ __launch_bounds__(ORD_BLOCK) void order_rank_kernel(const uint16_t *__restrict__ key, int64_t n_items, int32_t n_blocks,
+                                                               const int32_t *__restrict__ cnt, const int32_t *__restrict__ base,
+                                                               int32_t *__restrict__ rank, int32_t *__restrict__ item_at)
+{
+    __shared__ uint16_t s_key[ORD_BLOCK];
+    const int64_t i = (int64_t)blockIdx.x * ORD_BLOCK + threadIdx.x;
+    const uint16_t k = i < n_items ? key[i] : (uint16_t)0xFFFF;
+    s_key[threadIdx.x] = k;
+    __syncthreads();
+    if (i >= n_items) return;
+    int same = 0;   // earlier items of the block with the same key
+    for (int j = 0; j < (int)threadIdx.x; j++) same += s_key[j] == k ? 1 : 0;
+    const int32_t r = base[k] + cnt[(int64_t)k * n_blocks + blockIdx.x] + same;
+    rank[i] = r;
+    item_at[r] = (int32_t)i;
+}
+
+// inv[tree][row of the item] = the item's position in the tree's permutation
+__global__ __launch_bounds__(256) void order_inv_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ rank,
+                                                        int64_t n_items, int64_t total, int32_t *__restrict__ inv)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int64_t t = i / n_items;
+    inv[t * n_items + rank[perm[i]]] = (int32_t)(i - t * n_items);
+}
+
+// scratch slots 30..32: [rank | item_at], inv by row, the counting sort's table (+ keys).  The fp16 rows stay where they are:
+// a lane of the contraction fetches its row's address through item_at once (a copy of the image in row order cost 0.17 ms
+// of HBM time beside the second level's two_means).  Enqueued on `stream` (the side stream, under that two_means).
+int split_mm_order_rows(morna_index *h, const uint8_t *side, const int32_t *perm, int32_t n_trees, hipStream_t stream,
+                        const int32_t **rank_out, int32_t **inv_out)
+{
+    const int64_t N = h->n_items;
+    ScratchRef<int32_t> maps(h->scratch[30]), invr(h->scratch[31]), table(h->scratch[32]);
+    const int32_t n_blocks = (int32_t)((N + ORD_BLOCK - 1) / ORD_BLOCK);
+    MORNA_TRY(maps.alloc((size_t)N * 2));
+    MORNA_TRY(invr.alloc((size_t)n_trees * N));
+    MORNA_TRY(table.alloc((size_t)n_blocks * ORD_BINS + ORD_BINS + (size_t)(N + 1) / 2));
+    int32_t *key_base = table.p + (size_t)n_blocks * ORD_BINS;   // [ORD_BINS] items with a smaller key
+    uint16_t *key = (uint16_t *)(key_base + ORD_BINS);
+    int32_t *rank = maps.p, *item_at = maps.p + N;
+    const int n_bits = n_trees < ORD_BITS ? n_trees : ORD_BITS;
+    hipLaunchKernelGGL(order_key_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, side, N, n_bits, key);
+    hipLaunchKernelGGL(order_hist_kernel, dim3((unsigned)n_blocks), dim3(ORD_BLOCK), 0, stream, key, N, n_blocks, table.p);
+    hipLaunchKernelGGL(order_scan_bins_kernel, dim3(ORD_BINS / 4), dim3(256), 0, stream, table.p, n_blocks, key_base);
+    hipLaunchKernelGGL(order_scan_keys_kernel, dim3(1), dim3(1024), 0, stream, key_base);
+    hipLaunchKernelGGL(order_rank_kernel, dim3((unsigned)n_blocks), dim3(ORD_BLOCK), 0, stream, key, N, n_blocks, table.p, key_base, rank,
+                       item_at);
+    const int64_t total = (int64_t)n_trees * N;
+    hipLaunchKernelGGL(order_inv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, perm, rank, N, total, invr.p);
+    HIP_TRY(hipGetLastError());
+    h->ord_valid = true;
+    *rank_out = rank;
+    *inv_out = invr.p;
+    return MORNA_OK;
 }
 
 // scratch slots 19..23 of the handle: fp16 rows, their norms, fp16 hyperplanes of the level, their norms,
@@ -417,7 +569,13 @@ int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, co
     const int64_t N = h->n_items;
     ScratchRef<_Float16> x16(h->scratch[19]), h16(h->scratch[21]);
     ScratchRef<float> xn(h->scratch[20]), hn(h->scratch[22]);
+    ScratchRef<int32_t> maps(h->scratch[30]);
     ScratchRef<uint8_t> ambuf(h->scratch[23]);
+    // the rows of the contraction: the items in id order, or in the order split_mm_order_rows made (`inv` is then by row too)
+    const bool ord = h->ord_valid;
+    const _Float16 *rows16 = x16.p;
+    const float *rows_n = xn.p, *rows_e = xn.p + 2 * N;
+    const int32_t *rank = ord ? maps.p : nullptr, *item_at = ord ? maps.p + N : nullptr;
     const size_t cap = (size_t)N * h->n_trees;   // a row is in at most one split node per tree
     if (cap > 0xFFFFFFF0u) {
         set_error("split_mm_level: %lld x %d (row, tree) pairs exceed the open-pair list", (long long)N, h->n_trees);
@@ -436,7 +594,7 @@ int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, co
     static const bool big_on = !(getenv("MORNA_SPLIT_BIG") && atoi(getenv("MORNA_SPLIT_BIG")) == 0);
     // the tasks each row tile needs, from the second level of a tree on (MORNA_SPLIT_LISTS=0: every tile x every task)
     static const bool lists_on = !(getenv("MORNA_SPLIT_LISTS") && atoi(getenv("MORNA_SPLIT_LISTS")) == 0);
-    if (big_on && n_tasks >= 1024) {
+    if (big_on && (n_tasks >= 1024 || (ord && lists_on && n_tasks >= 512))) {
         const unsigned n_rt = (unsigned)((N + 255) / 256), n_ct = (unsigned)((n_tasks + 255) / 256);
         const int32_t *col_list = nullptr, *col_count = nullptr, *col_first = nullptr;
         if (lists_on) {
@@ -445,8 +603,8 @@ int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, co
             MORNA_TRY(active.alloc((size_t)n_rt * n_tasks));
             MORNA_TRY(lists.alloc((size_t)n_rt * n_tasks + 2 * n_rt + 1));
             HIP_TRY(hipMemsetAsync(active.p, 0, (size_t)n_rt * n_tasks, h->stream));
-            hipLaunchKernelGGL(split_active_mark_kernel, dim3((unsigned)n_tasks), dim3(256), 0, h->stream, d_tasks, perm, N, 8, n_tasks,
-                               active.p);
+            hipLaunchKernelGGL(split_active_mark_kernel, dim3((unsigned)n_tasks), dim3(256), 0, h->stream, d_tasks, perm, N, rank, 8,
+                               n_tasks, active.p);
             hipLaunchKernelGGL(split_active_list_kernel, dim3(n_rt), dim3(256), 0, h->stream, active.p, n_tasks, lists.p,
                                lists.p + (size_t)n_rt * n_tasks);
             col_list = lists.p;
@@ -457,19 +615,19 @@ int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, co
         }
         const float eps1 = (4.f * (float)h->dpad + 2.f) * 5.9604645e-8f + 4.1e-6f;   // EACC for ONE chain of dpad products
         HIP_TRY(hipFuncSetAttribute((const void *)split_mm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 256 * 4));
-        hipLaunchKernelGGL(split_mm_kernel<true>, dim3(8u * ((n_rt + 7) / 8) * n_ct), dim3(1024), 128 * 256 * 4, h->stream, x16.p, xn.p,
-                           xn.p + 2 * N, N, h->dpad, h16.p, hn.p, hn.p + n_tasks, n_tasks, d_tasks, inv, eps1, side, ones,
+        hipLaunchKernelGGL(split_mm_kernel<true>, dim3(8u * ((n_rt + 7) / 8) * n_ct), dim3(1024), 128 * 256 * 4, h->stream, rows16, rows_n,
+                           rows_e, N, h->dpad, h16.p, hn.p, hn.p + n_tasks, n_tasks, d_tasks, inv, item_at, eps1, side, ones,
                            amb_count, amb, (unsigned int)cap, col_list, col_count, col_first);
     } else {
         const unsigned n_rt = (unsigned)((N + 127) / 128), n_ct = (unsigned)((n_tasks + 127) / 128);
         static_assert(MM16_LDS == 128 * 128 * 4, "the slabs and the result tile share the dynamic LDS");
         HIP_TRY(hipFuncSetAttribute((const void *)split_mm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 4));
-        hipLaunchKernelGGL(split_mm_kernel<false>, dim3(8u * ((n_rt + 7) / 8) * n_ct), dim3(512), 128 * 128 * 4, h->stream, x16.p, xn.p,
-                           xn.p + 2 * N, N, h->dpad, h16.p, hn.p, hn.p + n_tasks, n_tasks, d_tasks, inv, sm_eps(h->dpad), side,
+        hipLaunchKernelGGL(split_mm_kernel<false>, dim3(8u * ((n_rt + 7) / 8) * n_ct), dim3(512), 128 * 128 * 4, h->stream, rows16, rows_n,
+                           rows_e, N, h->dpad, h16.p, hn.p, hn.p + n_tasks, n_tasks, d_tasks, inv, item_at, sm_eps(h->dpad), side,
                            ones, amb_count, amb, (unsigned int)cap, (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr);
     }
     hipLaunchKernelGGL(split_amb_kernel, dim3((unsigned)(4 * h->n_cus)), dim3(256), 0, h->stream, h->X.p, N, h->dpad, d_tasks,
-                       inv, seed, hp_level, amb_count, amb, (unsigned int)cap, side, ones);
+                       inv, seed, hp_level, amb_count, amb, (unsigned int)cap, side, ones, item_at);
     HIP_TRY(hipGetLastError());
     // MORNA_DEBUG_OPEN=1: how many (row, tree) pairs the filter of this level left to the canonical dot (stderr;
     // costs a synchronisation, measurement only)

@@ -4,8 +4,10 @@ to defeat them.  -m gpu
 The split of a level (splitmm.hip) and the candidate filter of the approximate search decide from fp16 copies only
 what they can PROVE and hand everything else to the canonical fp32 arithmetic, so switching them off must change
 nothing: whole-forest and search digests are compared across MORNA_SPLIT_MM = 0 / 1, MORNA_QUERY_FILTER = 0 / 1 and
-MORNA_QUERY_DENSE = 0 / 1 (the filter dots of a whole batch as one contraction, or candidate by candidate) -- separate
-processes: the switches are read once.  The rows:
+MORNA_QUERY_DENSE = 0 / 1 (the filter dots of a whole batch as one contraction, or candidate by candidate), and across
+MORNA_SPLIT_ORDER = 0 / 1 and MORNA_SPLIT_LISTS = 0 / 1 (the order of the rows of the split contraction, and the per-tile
+task lists: both only choose which products are computed; the 256-wide case with 150 trees has levels with enough split
+nodes for the lists) -- separate processes: the switches are read once.  The rows:
 
   * midpoints  s (a / |a| + b / |b|) of rows a, b from two different clusters: against the hyperplane that separates
     those clusters (the normalised difference of their centroids) the dot product cancels to ~1e-7 of |row| |h|, so
@@ -90,7 +92,7 @@ print("DIGEST", h.hexdigest(), st["n_split"], st["max_depth"])
 """
 
 
-@pytest.mark.parametrize("D,N,T", [(3000, 16000, 6), (8192, 34000, 3)])
+@pytest.mark.parametrize("D,N,T", [(3000, 16000, 6), (8192, 34000, 3), (256, 40000, 150)])
 def test_adversarial_rows_filters_change_nothing(tmp_path, D, N, T):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = str(tmp_path / "digest.py")
@@ -98,14 +100,15 @@ def test_adversarial_rows_filters_change_nothing(tmp_path, D, N, T):
         fh.write(_SCRIPT.format(root=root, N=N, D=D, T=T))
     out, open_lines = {}, []
     for name, extra in (("default", {"MORNA_DEBUG_OPEN": "1"}), ("no_mm", {"MORNA_SPLIT_MM": "0"}),
-                        ("no_qf", {"MORNA_QUERY_FILTER": "0"}), ("no_dense", {"MORNA_QUERY_DENSE": "0"})):
+                        ("no_qf", {"MORNA_QUERY_FILTER": "0"}), ("no_dense", {"MORNA_QUERY_DENSE": "0"}),
+                        ("no_order", {"MORNA_SPLIT_ORDER": "0"}), ("no_lists", {"MORNA_SPLIT_LISTS": "0", "MORNA_SPLIT_ORDER": "0"})):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         out[name] = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0].split()[1:]
         if name == "default":
             open_lines = [ln for ln in r.stderr.splitlines() if ln.startswith("[morna] split_mm level")]
-    assert out["default"] == out["no_mm"] == out["no_qf"] == out["no_dense"], out
+    assert out["default"] == out["no_mm"] == out["no_qf"] == out["no_dense"] == out["no_order"] == out["no_lists"], out
     assert int(out["default"][2]) >= 2                       # at least two levels went through the contraction
     assert open_lines, "the matrix-core split did not run"
     print("\n".join(open_lines))                             # pytest -s: the open-pair share per level
