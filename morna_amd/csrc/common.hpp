@@ -130,6 +130,8 @@ struct morna_index {
     uint32_t count_epoch = 0;
     uint8_t *host_out = nullptr;       // page-locked staging of query results
     size_t host_out_cap = 0;
+    uint8_t *host_tables = nullptr;    // page-locked staging of the node tables on their way to HBM (forest.hip)
+    size_t host_tables_cap = 0;
 
     // host staging of add_item() rows until build()
     std::vector<float> host_rows;  // [host_n][dim]

@@ -1150,6 +1150,29 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             return MORNA_OK;
         };
 
+        // the level's task list goes up through page-locked staging (the copy of an earlier attempt has long run: its
+        // counts have been read back since)
+        auto upload_tasks = [&](const std::vector<SplitTask> &tk) -> int {
+            const size_t bytes = tk.size() * sizeof(SplitTask);
+            if (bytes > h->host_tables_cap) {
+                if (hipStreamSynchronize(h->stream) != hipSuccess) return MORNA_E_HIP;
+                if (h->host_tables) (void)hipHostFree(h->host_tables);
+                h->host_tables = nullptr;
+                h->host_tables_cap = 0;
+                if (hipHostMalloc((void **)&h->host_tables, std::max<size_t>(bytes * 2, 1 << 16), hipHostMallocDefault) != hipSuccess) {
+                    set_error("forest build: hipHostMalloc of the task staging failed");
+                    return MORNA_E_HIP;
+                }
+                h->host_tables_cap = std::max<size_t>(bytes * 2, 1 << 16);
+            }
+            memcpy(h->host_tables, tk.data(), bytes);
+            if (hipMemcpyAsync(d_tasks.p, h->host_tables, bytes, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+                set_error("forest build: task upload failed");
+                return MORNA_E_HIP;
+            }
+            return MORNA_OK;
+        };
+
         for (int attempt = 0; attempt < 3 && !pending.empty(); attempt++) {
             const int32_t n_chunks = make_tasks(pending, attempt, tasks);
             const int32_t A = (int32_t)tasks.size();
@@ -1177,7 +1200,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             // MORNA_SPLIT_MM=0 turns it off (row-window / chunk forms as before).
             const bool use_mm = mm_on && attempt == 0 && max_per_tree >= 1 && max_per_tree <= 32 &&
                                 rows * 2 >= (int64_t)n_trees * N;
-            F_TRY(hipMemcpyAsync(d_tasks.p, tasks.data(), (size_t)A * sizeof(SplitTask), hipMemcpyHostToDevice, h->stream));
+            if ((rc = upload_tasks(tasks))) { cleanup(); return rc; }
             // (d_ones is zeroed by the two_means kernel of the attempt, task by task: a hipMemsetAsync costs ~15 us of
             // idle device around its few microseconds)
             bool side_work = false;
@@ -1329,7 +1352,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
         if (!fb.empty()) {
             make_tasks(fb, 3, tasks);
             const int32_t A = (int32_t)tasks.size();
-            F_TRY(hipMemcpyAsync(d_tasks.p, tasks.data(), (size_t)A * sizeof(SplitTask), hipMemcpyHostToDevice, h->stream));
+            if ((rc = upload_tasks(tasks))) { cleanup(); return rc; }
             hipLaunchKernelGGL(fallback_kernel, dim3((unsigned)A), dim3(256), 0, h->stream, d_tasks.p, N, dpad, seed,
                                side.p, d_ones.p, hp_level);
             F_TRY(hipGetLastError());
@@ -1370,12 +1393,30 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
         cleanup();
         return rc;
     }
-    F_TRY(hipMemcpyAsync(h->node_rec.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice, h->stream));
-    F_TRY(hipMemcpyAsync(h->node_tree.p, ntree.data(), ntree.size() * 4, hipMemcpyHostToDevice, h->stream));
-    F_TRY(hipMemcpyAsync(h->node_hp.p, nhp.data(), nhp.size() * 4, hipMemcpyHostToDevice, h->stream));
+    {
+        // through page-locked staging: a copy from the pageable vectors is staged by the runtime, ~20 us of host time each,
+        // and the device has nothing else to do just then
+        const size_t b_rec = rec.size() * 4, b_tree = ntree.size() * 4, b_hp = nhp.size() * 4, need = b_rec + b_tree + b_hp;
+        if (need > h->host_tables_cap) {
+            if (h->host_tables) {
+                if (h->ev_tables_pending) F_TRY(hipEventSynchronize(h->ev_tables));   // a copy out of the old buffer may be in flight
+                (void)hipHostFree(h->host_tables);
+            }
+            h->host_tables = nullptr;
+            h->host_tables_cap = 0;
+            F_TRY(hipHostMalloc((void **)&h->host_tables, need * 2, hipHostMallocDefault));
+            h->host_tables_cap = need * 2;
+        }
+        memcpy(h->host_tables, rec.data(), b_rec);
+        memcpy(h->host_tables + b_rec, ntree.data(), b_tree);
+        memcpy(h->host_tables + b_rec + b_tree, nhp.data(), b_hp);
+        F_TRY(hipMemcpyAsync(h->node_rec.p, h->host_tables, b_rec, hipMemcpyHostToDevice, h->stream));
+        F_TRY(hipMemcpyAsync(h->node_tree.p, h->host_tables + b_rec, b_tree, hipMemcpyHostToDevice, h->stream));
+        F_TRY(hipMemcpyAsync(h->node_hp.p, h->host_tables + b_rec + b_tree, b_hp, hipMemcpyHostToDevice, h->stream));
+    }
     // No wait here: the last partition and these copies are ordered on the handle's stream in front of whatever the caller
-    // does next with the handle (a search starts without the device draining first); the host tables they read belong to the
-    // handle and are next touched by another build, which settles first.  Blocking copies settle() as well.
+    // does next with the handle (a search starts without the device draining first); the staging they read belongs to the
+    // handle and is next written by another build, which waits for ev_tables first.  Blocking copies settle() as well.
     if (!h->ev_tables) F_TRY(hipEventCreateWithFlags(&h->ev_tables, hipEventDisableTiming));
     F_TRY(hipEventRecord(h->ev_tables, h->stream));
     h->ev_tables_pending = true;
