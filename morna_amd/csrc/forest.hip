@@ -877,6 +877,14 @@ __global__ void post_counts_kernel(const int32_t *__restrict__ ones, int32_t n, 
                            __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// the level's task list, pulled out of page-locked host memory by the device itself: a hipMemcpyAsync of more than a few KB
+// goes to the SDMA engine, ~20 us of start-up during which the stream has nothing else to run
+__global__ void pull_tasks_kernel(const int4 *__restrict__ src /* host memory, device-visible */, int4 *__restrict__ dst, int32_t n16)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
 template <int PT>
 __global__ __launch_bounds__(PT) void partition_kernel(const SplitTask *__restrict__ tasks, int64_t n_items,
                                                        const uint8_t *__restrict__ side,
@@ -1049,6 +1057,37 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
         }                                                           \
     } while (0)
 
+    // the node-table entries of the level just finished, written once the next level is under way (or at the end)
+    struct LateTables {
+        std::vector<Seg> parents;
+        std::vector<int32_t> ones;
+        int32_t first_id = 0;
+        int64_t first_hp = 0;
+        bool pending = false;
+    } late;
+    int32_t next_node_id = (int32_t)ntree.size();
+    auto write_late_tables = [&]() {
+        if (!late.pending) return;
+        late.pending = false;
+        const size_t S2 = late.parents.size();
+        rec.reserve(rec.size() + S2 * 8);
+        ntree.reserve(ntree.size() + S2 * 2);
+        nhp.reserve(nhp.size() + S2 * 2);
+        for (size_t i = 0; i < S2; i++) {
+            const Seg &s = late.parents[i];
+            const int32_t n1 = late.ones[i], n0 = s.count - n1;
+            const int32_t id0 = late.first_id + 2 * (int32_t)i, id1 = id0 + 1;
+            rec[(size_t)s.node * 4 + 0] = id0;
+            rec[(size_t)s.node * 4 + 1] = id1;
+            nhp[(size_t)s.node] = (int32_t)(late.first_hp + (int64_t)i);
+            rec.insert(rec.end(), {-1, -1, s.start, n0});
+            rec.insert(rec.end(), {-1, -1, s.start + n0, n1});
+            ntree.push_back(s.tree);
+            ntree.push_back(s.tree);
+            nhp.push_back(-1);
+            nhp.push_back(-1);
+        }
+    };
     while (!cur.empty()) {
         // split nodes of this level, in cur order
         std::vector<int32_t> split_idx;
@@ -1128,6 +1167,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 set_error("forest build: partition launch failed");
                 return MORNA_E_HIP;
             }
+            write_late_tables();   // the previous level's node-table entries, while this level's kernels run
             h_ones.resize((size_t)A);
             volatile unsigned long long *box = h->host_counts;
             int64_t spins = 0;
@@ -1159,14 +1199,22 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 if (h->host_tables) (void)hipHostFree(h->host_tables);
                 h->host_tables = nullptr;
                 h->host_tables_cap = 0;
-                if (hipHostMalloc((void **)&h->host_tables, std::max<size_t>(bytes * 2, 1 << 16), hipHostMallocDefault) != hipSuccess) {
+                if (hipHostMalloc((void **)&h->host_tables, std::max<size_t>(bytes * 2, 1 << 16), hipHostMallocMapped) != hipSuccess) {
                     set_error("forest build: hipHostMalloc of the task staging failed");
                     return MORNA_E_HIP;
                 }
                 h->host_tables_cap = std::max<size_t>(bytes * 2, 1 << 16);
             }
             memcpy(h->host_tables, tk.data(), bytes);
-            if (hipMemcpyAsync(d_tasks.p, h->host_tables, bytes, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+            static_assert(sizeof(SplitTask) % 16 == 0, "tasks are moved in 16-byte words");
+            void *dev_view = nullptr;
+            if (hipHostGetDevicePointer(&dev_view, h->host_tables, 0) != hipSuccess) {
+                set_error("forest build: the task staging is not visible to the device");
+                return MORNA_E_HIP;
+            }
+            const int32_t n16 = (int32_t)(bytes / 16);
+            if (n16 > 0) hipLaunchKernelGGL(pull_tasks_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, h->stream, (const int4 *)dev_view, (int4 *)d_tasks.p, n16);
+            if (hipGetLastError() != hipSuccess) {
                 set_error("forest build: task upload failed");
                 return MORNA_E_HIP;
             }
@@ -1362,29 +1410,31 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             for (int32_t a = 0; a < A; a++) final_ones[(size_t)fb[(size_t)a]] = h_ones[(size_t)a];
             h->stats.fallback_nodes += A;
         }
-        // children: ids base + 2*i + side for the i-th split node of the level
+        // children: ids base + 2*i + side for the i-th split node of the level.  Only the segments the NEXT level is cut
+        // from are made now; the node table's entries (a few thousand vector appends) wait until that level's kernels
+        // have been enqueued -- the device is idle while the host stands between a level's counts and the next launch
         nxt.clear();
+        nxt.reserve((size_t)S * 2);
+        late.parents.resize((size_t)S);
+        late.ones.assign(final_ones.begin(), final_ones.end());
+        late.first_id = next_node_id;
+        late.first_hp = n_split_total;
         for (int32_t i = 0; i < S; i++) {
             const Seg &s = cur[(size_t)split_idx[(size_t)i]];
             const int32_t n1 = final_ones[(size_t)i], n0 = s.count - n1;
-            const int32_t id0 = (int32_t)ntree.size(), id1 = id0 + 1;
-            rec[(size_t)s.node * 4 + 0] = id0;
-            rec[(size_t)s.node * 4 + 1] = id1;
-            nhp[(size_t)s.node] = (int32_t)(n_split_total + i);
-            rec.insert(rec.end(), {-1, -1, s.start, n0});
-            rec.insert(rec.end(), {-1, -1, s.start + n0, n1});
-            ntree.push_back(s.tree);
-            ntree.push_back(s.tree);
-            nhp.push_back(-1);
-            nhp.push_back(-1);
+            const int32_t id0 = next_node_id + 2 * i, id1 = id0 + 1;
+            late.parents[(size_t)i] = s;
             nxt.push_back(Seg{s.tree, s.level + 1, s.start, n0, id0});
             nxt.push_back(Seg{s.tree, s.level + 1, s.start + n0, n1, id1});
         }
+        next_node_id += 2 * S;
+        late.pending = true;
         n_split_total += S;
         cur.swap(nxt);
         level++;
     }
 
+    write_late_tables();
     // consolidate hyperplanes and node tables in HBM
     h->n_split = n_split_total;
     h->n_nodes = (int64_t)ntree.size();
@@ -1396,7 +1446,8 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
     {
         // through page-locked staging: a copy from the pageable vectors is staged by the runtime, ~20 us of host time each,
         // and the device has nothing else to do just then
-        const size_t b_rec = rec.size() * 4, b_tree = ntree.size() * 4, b_hp = nhp.size() * 4, need = b_rec + b_tree + b_hp;
+        const size_t b_rec = rec.size() * 4, b_tree = ntree.size() * 4, b_hp = nhp.size() * 4;
+        const size_t o_tree = b_rec /* 16 bytes per node */, o_hp = (o_tree + b_tree + 15) / 16 * 16, need = o_hp + b_hp;
         if (need > h->host_tables_cap) {
             if (h->host_tables) {
                 if (h->ev_tables_pending) F_TRY(hipEventSynchronize(h->ev_tables));   // a copy out of the old buffer may be in flight
@@ -1404,15 +1455,29 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             }
             h->host_tables = nullptr;
             h->host_tables_cap = 0;
-            F_TRY(hipHostMalloc((void **)&h->host_tables, need * 2, hipHostMallocDefault));
+            F_TRY(hipHostMalloc((void **)&h->host_tables, need * 2, hipHostMallocMapped));
             h->host_tables_cap = need * 2;
         }
         memcpy(h->host_tables, rec.data(), b_rec);
-        memcpy(h->host_tables + b_rec, ntree.data(), b_tree);
-        memcpy(h->host_tables + b_rec + b_tree, nhp.data(), b_hp);
-        F_TRY(hipMemcpyAsync(h->node_rec.p, h->host_tables, b_rec, hipMemcpyHostToDevice, h->stream));
-        F_TRY(hipMemcpyAsync(h->node_tree.p, h->host_tables + b_rec, b_tree, hipMemcpyHostToDevice, h->stream));
-        F_TRY(hipMemcpyAsync(h->node_hp.p, h->host_tables + b_rec + b_tree, b_hp, hipMemcpyHostToDevice, h->stream));
+        memcpy(h->host_tables + o_tree, ntree.data(), b_tree);
+        memcpy(h->host_tables + o_hp, nhp.data(), b_hp);
+        // (pulled by the device, as the task lists are; the three tables are whole 16-byte words apart from their tails)
+        void *dev_view = nullptr;
+        F_TRY(hipHostGetDevicePointer(&dev_view, h->host_tables, 0));
+        const uint8_t *dv = (const uint8_t *)dev_view;
+        auto pull = [&](void *dst, const uint8_t *src, size_t bytes) -> hipError_t {
+            const int32_t n16 = (int32_t)(bytes / 16);
+            if (n16 > 0)
+                hipLaunchKernelGGL(pull_tasks_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, h->stream, (const int4 *)src,
+                                   (int4 *)dst, n16);
+            if (bytes % 16)   // the tail, if any
+                return hipMemcpyAsync((uint8_t *)dst + (size_t)n16 * 16, h->host_tables + (src - dv) + (size_t)n16 * 16, bytes % 16,
+                                      hipMemcpyHostToDevice, h->stream);
+            return hipGetLastError();
+        };
+        F_TRY(pull(h->node_rec.p, dv, b_rec));
+        F_TRY(pull(h->node_tree.p, dv + o_tree, b_tree));
+        F_TRY(pull(h->node_hp.p, dv + o_hp, b_hp));
     }
     // No wait here: the last partition and these copies are ordered on the handle's stream in front of whatever the caller
     // does next with the handle (a search starts without the device draining first); the staging they read belongs to the
