@@ -98,6 +98,11 @@ struct Seg {
     int32_t tree, level, start, count, node;
 };
 
+// Where a node's items are DURING a build: the work buffer holds two images of every tree's permutation, [tree][2][n_items],
+// and a node of depth `level` has its items in image (level & 1) -- a partition reads one image and writes the node's two
+// children into the other, so nothing is copied back (forest.hip; the leaves are gathered into h->perm at the end).
+#define TASK_ITEMS_AT(t, n_items) (((int64_t)(t).tree * 2 + ((t).level & 1)) * (int64_t)(n_items) + (t).start)
+
 struct Timer {
     double ms = 0;
     int64_t launches = 0, bytes = 0;
@@ -177,7 +182,7 @@ struct morna_index {
     morna::DevBuf<uint8_t> ws;
     // build scratch kept between calls (feature and forest builds reuse it instead of
     // hipMalloc / hipFree on every call); slots are named in features.hip / forest.hip
-    morna::DevBuf<uint8_t> scratch[34];
+    morna::DevBuf<uint8_t> scratch[35];
     // [0] rows read by query kernels (hyperplane dots + candidates + 1 per query)
     morna::DevBuf<unsigned long long> d_stat;
 
@@ -242,7 +247,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed);
 int split_mm_prepare_rows(morna_index *h, hipStream_t stream);   // stream: the handle's main or side stream
 int split_mm_convert_rows(morna_index *h, const float *src, int64_t rows, _Float16 *dst, float *norm, float *err,
                           float *inv_scale, hipStream_t stream);
-int split_mm_order_rows(morna_index *h, const uint8_t *side, const int32_t *perm, int32_t n_trees, hipStream_t stream,
+int split_mm_order_rows(morna_index *h, const uint8_t *side, const int32_t *inv_by_item, int32_t n_trees, hipStream_t stream,
                         const int32_t **rank_out, int32_t **inv_out);
 int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, const float *hp_level,
                    const int32_t *perm, const int32_t *inv, uint32_t seed, uint8_t *side, int32_t *ones);

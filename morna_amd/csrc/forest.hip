@@ -81,7 +81,7 @@ __global__ __launch_bounds__(TM_THREADS) void two_means_kernel(const float *__re
     const SplitTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const int nvec = dpad / 4;
-    const int32_t *items = perm + (int64_t)t.tree * n_items + t.start;
+    const int32_t *items = perm + TASK_ITEMS_AT(t, n_items);
     Kiss32 rng(node_seed(seed, (uint32_t)t.tree, (uint32_t)t.level, (uint32_t)t.start, (uint32_t)t.attempt));
 
     // two distinct random items seed the centroids
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, 3) void two_means_wave_kernel(const float *__r
     if (lane == 0) ones[ti] = 0;   // the split kernels that follow count this task's right side here
     const SplitTask t = tasks[ti];
     const int nvec = dpad / 4;
-    const int32_t *items = perm + (int64_t)t.tree * n_items + t.start;
+    const int32_t *items = perm + TASK_ITEMS_AT(t, n_items);
     Kiss32 rng(node_seed(seed, (uint32_t)t.tree, (uint32_t)t.level, (uint32_t)t.start, (uint32_t)t.attempt));
 
     uint32_t i = rng.index((uint32_t)t.count);
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void two_means_strip_kernel(const float *__res
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
     const int L = 16 * w + (lane >> 2);   // the canonical lane this lane's chain belongs to
     const SplitTask t = tasks[blockIdx.x];
-    const int32_t *items = perm + (int64_t)t.tree * n_items + t.start;
+    const int32_t *items = perm + TASK_ITEMS_AT(t, n_items);
     // every wave runs the node's Kiss32 stream itself: no index is exchanged
     Kiss32 rng(node_seed(seed, (uint32_t)t.tree, (uint32_t)t.level, (uint32_t)t.start, (uint32_t)t.attempt));
     const float *Xs = X + 64 * w + lane;   // this lane's element of k-step 0 of row 0
@@ -563,7 +563,7 @@ __global__ void sched_bucket_kernel(const SplitTask *__restrict__ tasks, int32_t
     }
     const SplitTask t = tasks[lo];
     const int pos0 = (c - t.chunk0) * 64;
-    const int64_t first = perm[(int64_t)t.tree * n_items + t.start + pos0];
+    const int64_t first = perm[TASK_ITEMS_AT(t, n_items) + pos0];
     const int b = (int)(first * n_buckets / n_items);
     atomicAdd(&hist[b], 1);
     info[c] = make_int2(lo, b);
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(SP_THREADS) void split_kernel(const float *__restri
     if (tid == 0) s_ones = 0;
     __syncthreads();
 
-    const int32_t *items = perm + (int64_t)t.tree * n_items + t.start + pos0;
+    const int32_t *items = perm + TASK_ITEMS_AT(t, n_items) + pos0;
     uint8_t *sd = side + (int64_t)t.tree * n_items + t.start + pos0;
     const uint32_t nseed = node_seed(seed, (uint32_t)t.tree, (uint32_t)t.level, (uint32_t)t.start, (uint32_t)t.attempt);
     int my_ones = 0;
@@ -705,7 +705,7 @@ __global__ void invert_kernel(const SplitTask *__restrict__ tasks, int32_t n_tas
     const SplitTask t = tasks[a];
     const int p = (c - t.chunk0) * 64 + threadIdx.x;
     if (p < t.count) {
-        const int64_t row = perm[(int64_t)t.tree * n_items + t.start + p];
+        const int64_t row = perm[TASK_ITEMS_AT(t, n_items) + p];
         row_task[(int64_t)t.tree * n_items + row] = a;
         row_pos[(int64_t)t.tree * n_items + row] = p;
     }
@@ -888,8 +888,8 @@ __global__ void pull_tasks_kernel(const int4 *__restrict__ src /* host memory, d
 template <int PT>
 __global__ __launch_bounds__(PT) void partition_kernel(const SplitTask *__restrict__ tasks, int64_t n_items,
                                                        const uint8_t *__restrict__ side,
-                                                       const int32_t *__restrict__ ones, int32_t *__restrict__ perm,
-                                                       int32_t *__restrict__ tmp, int32_t *__restrict__ inv,
+                                                       const int32_t *__restrict__ ones, int32_t *__restrict__ perm /* work buffer [tree][2][n_items] */,
+                                                       int32_t *__restrict__ inv,
                                                        const int32_t *__restrict__ rank /* inv is indexed by rank[item] (or null: by item) */)
 {
     __shared__ int s_w1[PT / WAVE];
@@ -897,7 +897,10 @@ __global__ __launch_bounds__(PT) void partition_kernel(const SplitTask *__restri
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const int n1 = ones[blockIdx.x], n0 = t.count - n1;
     if (!sides_stand(t.attempt, n0, n1)) return;   // uniform over the workgroup
-    const int64_t base = (int64_t)t.tree * n_items + t.start;
+    const int64_t base = (int64_t)t.tree * n_items + t.start;   // of the node's side bytes (and of its positions in `inv`)
+    // the node's items are read from the image of its depth and its children are written into the other one: no copy back
+    const int32_t *src = perm + TASK_ITEMS_AT(t, n_items);
+    int32_t *dst_img = perm + ((int64_t)t.tree * 2 + ((t.level + 1) & 1)) * n_items + t.start;
     // PT_PER consecutive positions per thread and round: a round costs two barriers whatever it moves, and with one
     // position per thread the root level took 49 of them (0.08 ms).  Ranks: right-side and valid counts of a thread
     // packed into one integer (16 bits each: a round has at most 4096 positions), scanned over the wave, wave totals
@@ -933,8 +936,8 @@ __global__ __launch_bounds__(PT) void partition_kernel(const SplitTask *__restri
         for (int u = 0; u < PT_PER; u++)
             if (sd[u] >= 0) {
                 const int dst = sd[u] ? (n0 + run1 + r1) : (run0 + (rv - r1));
-                const int32_t item = perm[base + pb + u];
-                tmp[base + dst] = item;
+                const int32_t item = src[pb + u];
+                dst_img[dst] = item;
                 if (inv) inv[(int64_t)t.tree * n_items + (rank ? rank[item] : item)] = t.start + dst;
                 r1 += sd[u];
                 rv += 1;
@@ -943,25 +946,30 @@ __global__ __launch_bounds__(PT) void partition_kernel(const SplitTask *__restri
         run0 += (total >> 16) - (total & 0xffff);
         __syncthreads();
     }
-    __syncthreads();
-    // copy back, four independent loads in flight per thread
-    for (int p = tid; p < t.count; p += PT * 4) {
-        int v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = p + u * PT < t.count ? tmp[base + p + u * PT] : 0;
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (p + u * PT < t.count) perm[base + p + u * PT] = v[u];
-    }
 }
 
-__global__ void iota_perm_kernel(int32_t *perm, int32_t *inv, int64_t n_items, int64_t total)
+// roots: image 0 of every tree = the identity
+__global__ void iota_perm_kernel(int32_t *perm /* work buffer [tree][2][n_items] */, int32_t *inv, int64_t n_items, int64_t total)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) {
-        perm[i] = (int32_t)(i % n_items);
-        if (inv) inv[i] = (int32_t)(i % n_items);
+        const int64_t t = i / n_items, r = i - t * n_items;
+        perm[t * 2 * n_items + r] = (int32_t)r;
+        if (inv) inv[i] = (int32_t)r;
     }
+}
+
+// the finished forest's leaves, out of the image of their depth into the permutation the searches read: one workgroup per leaf
+struct LeafSeg {
+    int32_t tree, level, start, count;
+};
+__global__ __launch_bounds__(256) void gather_leaves_kernel(const LeafSeg *__restrict__ leaves, const int32_t *__restrict__ work,
+                                                            int64_t n_items, int32_t *__restrict__ perm)
+{
+    const LeafSeg l = leaves[blockIdx.x];
+    const int32_t *src = work + ((int64_t)l.tree * 2 + (l.level & 1)) * n_items + l.start;
+    int32_t *dst = perm + (int64_t)l.tree * n_items + l.start;
+    for (int i = threadIdx.x; i < l.count; i += 256) dst[i] = src[i];
 }
 
 // -------------------------------------------------------------- host driver
@@ -1000,10 +1008,10 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
 
     MORNA_TRY(h->perm.alloc((size_t)n_trees * N));
     // scratch lives in the handle: a rebuild (or the next level) reuses it without hipMalloc
-    ScratchRef<int32_t> tmp(h->scratch[8]), d_ones(h->scratch[9]);
+    ScratchRef<int32_t> work(h->scratch[8]), d_ones(h->scratch[9]);   // work: two images of every tree's permutation (TASK_ITEMS_AT)
     ScratchRef<uint8_t> side(h->scratch[10]);
     ScratchRef<SplitTask> d_tasks(h->scratch[11]);
-    MORNA_TRY(tmp.alloc((size_t)n_trees * N));
+    MORNA_TRY(work.alloc((size_t)n_trees * N * 2));
     MORNA_TRY(side.alloc((size_t)n_trees * N));
     // launch-order scratch of the split kernel: buckets of 32 row ids
     ScratchRef<int32_t> d_hist(h->scratch[12]), d_cursor(h->scratch[13]);
@@ -1024,7 +1032,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
     std::vector<int32_t> tree_first;
     {
         const int64_t total = (int64_t)n_trees * N;
-        hipLaunchKernelGGL(iota_perm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->perm.p, inv_p, N, total);
+        hipLaunchKernelGGL(iota_perm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, work.p, inv_p, N, total);
         HIP_TRY(hipGetLastError());
     }
 
@@ -1066,6 +1074,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
         bool pending = false;
     } late;
     int32_t next_node_id = (int32_t)ntree.size();
+    std::vector<LeafSeg> leaves;   // where each finished leaf's items are (gather_leaves_kernel)
     auto write_late_tables = [&]() {
         if (!late.pending) return;
         late.pending = false;
@@ -1091,8 +1100,10 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
     while (!cur.empty()) {
         // split nodes of this level, in cur order
         std::vector<int32_t> split_idx;
-        for (size_t i = 0; i < cur.size(); i++)
+        for (size_t i = 0; i < cur.size(); i++) {
             if (cur[i].count > K) split_idx.push_back((int32_t)i);
+            else leaves.push_back(LeafSeg{cur[i].tree, cur[i].level, cur[i].start, cur[i].count});
+        }
         h->stats.max_depth = std::max<int64_t>(h->stats.max_depth, level);
         if (split_idx.empty()) break;
         const int32_t S = (int32_t)split_idx.size();
@@ -1158,10 +1169,10 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 ScopedTimer tm(h, MORNA_T_PARTITION, 0);
                 if (level_rows >= (int64_t)A * 2048)
                     hipLaunchKernelGGL(partition_kernel<1024>, dim3((unsigned)A), dim3(1024), 0, h->stream, d_tasks.p, N, side.p,
-                                       d_ones.p, h->perm.p, tmp.p, inv_p, rank_p);
+                                       d_ones.p, work.p, inv_p, rank_p);
                 else
                     hipLaunchKernelGGL(partition_kernel<256>, dim3((unsigned)A), dim3(256), 0, h->stream, d_tasks.p, N, side.p,
-                                       d_ones.p, h->perm.p, tmp.p, inv_p, rank_p);
+                                       d_ones.p, work.p, inv_p, rank_p);
             }
             if (hipGetLastError() != hipSuccess) {
                 set_error("forest build: partition launch failed");
@@ -1268,7 +1279,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 // kept by row (splitmm.hip, split_mm_order_rows)
                 F_TRY(hipEventRecord(h->ev_fork, h->stream));
                 F_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-                if ((rc = split_mm_order_rows(h, side.p, h->perm.p, n_trees, h->stream2, &rank_p, &inv_p))) { cleanup(); return rc; }
+                if ((rc = split_mm_order_rows(h, side.p, inv_p, n_trees, h->stream2, &rank_p, &inv_p))) { cleanup(); return rc; }
                 F_TRY(hipEventRecord(h->ev_join, h->stream2));
                 side_work = true;
             } else if (use_rw && !use_mm) {
@@ -1281,7 +1292,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 if (rows != (int64_t)n_trees * N)   // rows outside every split node must read "no task"
                     F_TRY(hipMemsetAsync(row_task.p, 0xFF, (size_t)n_trees * N * 4, h->stream2));
                 hipLaunchKernelGGL(invert_kernel, dim3((unsigned)n_chunks), dim3(64), 0, h->stream2, d_tasks.p, A, n_chunks,
-                                   h->perm.p, N, row_task.p, row_pos.p);
+                                   work.p, N, row_task.p, row_pos.p);
                 F_TRY(hipEventRecord(h->ev_join, h->stream2));
                 side_work = true;
             }
@@ -1291,7 +1302,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 const unsigned wg = (unsigned)((A + 3) / 4);
 #define TMW_LAUNCH(NVV)                                                                                              \
     hipLaunchKernelGGL(two_means_wave_kernel<NVV>, dim3(wg), dim3(256), 0, h->stream, h->X.p, h->rowinfo.p, N, dpad, \
-                       h->perm.p, d_tasks.p, A, seed, hp_level, d_ones.p)
+                       work.p, d_tasks.p, A, seed, hp_level, d_ones.p)
                 // Four waves per node (strips) while the level's nodes fit the chip at once (2 workgroups per CU): the
                 // node's 200-step chain is then 2-3x shorter (C3: 0.32 / 0.28 ms instead of 0.7 ms at the two
                 // shallowest levels).  Deeper levels are bound by the HBM gather of the rows (C3, 1600 nodes: 5.9 TB/s)
@@ -1300,7 +1311,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 const bool tm_strip = tm_strip_on && A <= 2 * h->n_cus;
 #define TMS_LAUNCH(NVV)                                                                                                 \
     hipLaunchKernelGGL((two_means_strip_kernel<NVV, TM_STRIP_DEPTH>), dim3((unsigned)A), dim3(256), 0, h->stream, h->X.p, \
-                       h->rowinfo.p, N, dpad, h->perm.p, d_tasks.p, seed, hp_level, d_ones.p)
+                       h->rowinfo.p, N, dpad, work.p, d_tasks.p, seed, hp_level, d_ones.p)
                 if (tm_strip && nvq == 12) TMS_LAUNCH(12);
                 else if (tm_strip && nvq == 8) TMS_LAUNCH(8);
                 else if (tm_strip && nvq == 4) TMS_LAUNCH(4);
@@ -1318,7 +1329,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 else if (nvq == 12) TMW_LAUNCH(12);
                 else   // other row lengths (or too long for the register file): centroids in LDS, one workgroup per node
                     hipLaunchKernelGGL(two_means_kernel, dim3((unsigned)A), dim3(TM_THREADS), (size_t)dpad * 4 * 3, h->stream,
-                                       h->X.p, h->norm2.p, N, dpad, h->perm.p, d_tasks.p, seed, hp_level, d_ones.p);
+                                       h->X.p, h->norm2.p, N, dpad, work.p, d_tasks.p, seed, hp_level, d_ones.p);
 #undef TMW_LAUNCH
 #undef TMS_LAUNCH
             }
@@ -1327,7 +1338,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 if ((rc = d_info.alloc((size_t)n_chunks)) || (rc = d_sched.alloc((size_t)n_chunks))) { cleanup(); return rc; }
                 F_TRY(hipMemsetAsync(d_hist.p, 0, (size_t)n_buckets * 4, h->stream));
                 const unsigned cb = (unsigned)((n_chunks + 255) / 256);
-                hipLaunchKernelGGL(sched_bucket_kernel, dim3(cb), dim3(256), 0, h->stream, d_tasks.p, A, n_chunks, h->perm.p, N,
+                hipLaunchKernelGGL(sched_bucket_kernel, dim3(cb), dim3(256), 0, h->stream, d_tasks.p, A, n_chunks, work.p, N,
                                    n_buckets, d_hist.p, d_info.p);
                 hipLaunchKernelGGL(sched_scan_kernel, dim3(1), dim3(1024), 0, h->stream, d_hist.p, n_buckets, d_cursor.p);
                 hipLaunchKernelGGL(sched_scatter_kernel, dim3(cb), dim3(256), 0, h->stream, d_tasks.p, n_chunks, d_info.p,
@@ -1336,7 +1347,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             if (side_work) F_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
             if (use_mm) {
                 ScopedTimer tm(h, MORNA_T_SPLIT, 4 * (int64_t)D * (rows + A));
-                if ((rc = split_mm_level(h, d_tasks.p, A, hp_level, h->perm.p, inv_p, seed, side.p, d_ones.p))) {
+                if ((rc = split_mm_level(h, d_tasks.p, A, hp_level, work.p, inv_p, seed, side.p, d_ones.p))) {
                     cleanup();
                     return rc;
                 }
@@ -1376,7 +1387,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 ScopedTimer tm(h, MORNA_T_SPLIT, 4 * (int64_t)D * (rows + A));
                 const unsigned grid = 8u * (unsigned)((n_chunks + 7) / 8);
                 hipLaunchKernelGGL(split_kernel, dim3(grid), dim3(SP_THREADS), (size_t)dpad * 4, h->stream, h->X.p, N, dpad,
-                                   h->perm.p, d_tasks.p, d_sched.p, n_chunks, seed, hp_level, side.p, d_ones.p);
+                                   work.p, d_tasks.p, d_sched.p, n_chunks, seed, hp_level, side.p, d_ones.p);
             }
             F_TRY(hipGetLastError());
             if ((rc = partition_and_fetch_counts(A, rows))) { cleanup(); return rc; }
@@ -1446,11 +1457,14 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
     {
         // through page-locked staging: a copy from the pageable vectors is staged by the runtime, ~20 us of host time each,
         // and the device has nothing else to do just then
-        const size_t b_rec = rec.size() * 4, b_tree = ntree.size() * 4, b_hp = nhp.size() * 4;
-        const size_t o_tree = b_rec /* 16 bytes per node */, o_hp = (o_tree + b_tree + 15) / 16 * 16, need = o_hp + b_hp;
+        const size_t b_rec = rec.size() * 4, b_tree = ntree.size() * 4, b_hp = nhp.size() * 4, b_leaf = leaves.size() * sizeof(LeafSeg);
+        const size_t o_tree = b_rec /* 16 bytes per node */, o_hp = (o_tree + b_tree + 15) / 16 * 16, o_leaf = (o_hp + b_hp + 15) / 16 * 16,
+                     need = o_leaf + b_leaf;
+        static_assert(sizeof(LeafSeg) == 16, "leaves are moved in 16-byte words");
         if (need > h->host_tables_cap) {
             if (h->host_tables) {
                 if (h->ev_tables_pending) F_TRY(hipEventSynchronize(h->ev_tables));   // a copy out of the old buffer may be in flight
+                F_TRY(hipStreamSynchronize(h->stream));                               // (or a task list being pulled)
                 (void)hipHostFree(h->host_tables);
             }
             h->host_tables = nullptr;
@@ -1461,7 +1475,8 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
         memcpy(h->host_tables, rec.data(), b_rec);
         memcpy(h->host_tables + o_tree, ntree.data(), b_tree);
         memcpy(h->host_tables + o_hp, nhp.data(), b_hp);
-        // (pulled by the device, as the task lists are; the three tables are whole 16-byte words apart from their tails)
+        memcpy(h->host_tables + o_leaf, leaves.data(), b_leaf);
+        // (pulled by the device, as the task lists are; the tables are whole 16-byte words apart from their tails)
         void *dev_view = nullptr;
         F_TRY(hipHostGetDevicePointer(&dev_view, h->host_tables, 0));
         const uint8_t *dv = (const uint8_t *)dev_view;
@@ -1475,6 +1490,14 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                                       hipMemcpyHostToDevice, h->stream);
             return hipGetLastError();
         };
+        // the leaves first: their items go from the work images into the permutation the searches read
+        ScratchRef<uint8_t> d_leaves(h->scratch[34]);
+        if ((rc = d_leaves.alloc(std::max<size_t>(b_leaf, 16)))) { cleanup(); return rc; }
+        F_TRY(pull(d_leaves.p, dv + o_leaf, b_leaf));
+        if (!leaves.empty())
+            hipLaunchKernelGGL(gather_leaves_kernel, dim3((unsigned)leaves.size()), dim3(256), 0, h->stream, (const LeafSeg *)d_leaves.p,
+                               work.p, N, h->perm.p);
+        F_TRY(hipGetLastError());
         F_TRY(pull(h->node_rec.p, dv, b_rec));
         F_TRY(pull(h->node_tree.p, dv + o_tree, b_tree));
         F_TRY(pull(h->node_hp.p, dv + o_hp, b_hp));

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void split_active_mark_kernel(const SplitTask 
                                                                 int tile_shift, int32_t n_tasks, uint8_t *__restrict__ active)
 {
     const SplitTask t = tasks[blockIdx.x];
-    const int32_t *items = perm + (int64_t)t.tree * n_items + t.start;
+    const int32_t *items = perm + TASK_ITEMS_AT(t, n_items);
     // neighbours in a node's list are often in the same tile (ids ascend along the list; ordered rows keep much of that):
     // only the first item of a run in the same tile stores.  The previous item's tile comes from the lane below.
     const int lane = threadIdx.x & (WAVE - 1);
@@ -495,20 +495,20 @@ __global__ __launch_bounds__(ORD_BLOCK) void order_rank_kernel(const uint16_t *_
     item_at[r] = (int32_t)i;
 }
 
-// inv[tree][row of the item] = the item's position in the tree's permutation
-__global__ __launch_bounds__(256) void order_inv_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ rank,
+// inv by row from inv by item: inv_r[tree][rank[item]] = inv[tree][item]
+__global__ __launch_bounds__(256) void order_inv_kernel(const int32_t *__restrict__ inv_by_item, const int32_t *__restrict__ rank,
                                                         int64_t n_items, int64_t total, int32_t *__restrict__ inv)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int64_t t = i / n_items;
-    inv[t * n_items + rank[perm[i]]] = (int32_t)(i - t * n_items);
+    const int64_t t = i / n_items, item = i - t * n_items;
+    inv[t * n_items + rank[item]] = inv_by_item[i];
 }
 
 // scratch slots 30..32: [rank | item_at], inv by row, the counting sort's table (+ keys).  The fp16 rows stay where they are:
 // a lane of the contraction fetches its row's address through item_at once (a copy of the image in row order cost 0.17 ms
 // of HBM time beside the second level's two_means).  Enqueued on `stream` (the side stream, under that two_means).
-int split_mm_order_rows(morna_index *h, const uint8_t *side, const int32_t *perm, int32_t n_trees, hipStream_t stream,
+int split_mm_order_rows(morna_index *h, const uint8_t *side, const int32_t *inv_by_item, int32_t n_trees, hipStream_t stream,
                         const int32_t **rank_out, int32_t **inv_out)
 {
     const int64_t N = h->n_items;
@@ -528,7 +528,7 @@ int split_mm_order_rows(morna_index *h, const uint8_t *side, const int32_t *perm
     hipLaunchKernelGGL(order_rank_kernel, dim3((unsigned)n_blocks), dim3(ORD_BLOCK), 0, stream, key, N, n_blocks, table.p, key_base, rank,
                        item_at);
     const int64_t total = (int64_t)n_trees * N;
-    hipLaunchKernelGGL(order_inv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, perm, rank, N, total, invr.p);
+    hipLaunchKernelGGL(order_inv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, inv_by_item, rank, N, total, invr.p);
     HIP_TRY(hipGetLastError());
     h->ord_valid = true;
     *rank_out = rank;
