@@ -907,15 +907,28 @@ __global__ __launch_bounds__(PT) void partition_kernel(const SplitTask *__restri
     // through LDS.
     constexpr int PT_PER = 4;
     int run0 = 0, run1 = 0;   // items already placed on each side
-    for (int p0 = 0; p0 < t.count; p0 += PT * PT_PER) {
+    // a round's sides and items are asked for one round ahead (they depend on nothing the round before computes): the
+    // kernel is a chain of memory round trips, three per round when each waits for the one before
+    int sd_n[PT_PER], it_n[PT_PER];
+    auto fetch = [&](int p0) {
         const int pb = p0 + tid * PT_PER;
-        int sd[PT_PER], pk = 0;
 #pragma unroll
         for (int u = 0; u < PT_PER; u++) {
             const bool valid = pb + u < t.count;
-            sd[u] = valid ? (int)side[base + pb + u] : -1;
-            pk += valid ? (sd[u] ? 0x10001 : 0x10000) : 0;
+            sd_n[u] = valid ? (int)side[base + pb + u] : -1;
+            it_n[u] = valid ? src[pb + u] : 0;
         }
+    };
+    fetch(0);
+    for (int p0 = 0; p0 < t.count; p0 += PT * PT_PER) {
+        int sd[PT_PER], it[PT_PER], pk = 0;
+#pragma unroll
+        for (int u = 0; u < PT_PER; u++) {
+            sd[u] = sd_n[u];
+            it[u] = it_n[u];
+            pk += sd[u] >= 0 ? (sd[u] ? 0x10001 : 0x10000) : 0;
+        }
+        if (p0 + PT * PT_PER < t.count) fetch(p0 + PT * PT_PER);   // uniform
         int incl = pk;
 #pragma unroll
         for (int o = 1; o < WAVE; o <<= 1) {
@@ -932,13 +945,15 @@ __global__ __launch_bounds__(PT) void partition_kernel(const SplitTask *__restri
         }
         const int excl = incl - pk + before;
         int r1 = excl & 0xffff, rv = excl >> 16;   // right-side / valid positions before this thread's first
+        int rk[PT_PER];
+#pragma unroll
+        for (int u = 0; u < PT_PER; u++) rk[u] = (rank && sd[u] >= 0) ? rank[it[u]] : it[u];   // the four look-ups together
 #pragma unroll
         for (int u = 0; u < PT_PER; u++)
             if (sd[u] >= 0) {
                 const int dst = sd[u] ? (n0 + run1 + r1) : (run0 + (rv - r1));
-                const int32_t item = src[pb + u];
-                dst_img[dst] = item;
-                if (inv) inv[(int64_t)t.tree * n_items + (rank ? rank[item] : item)] = t.start + dst;
+                dst_img[dst] = it[u];
+                if (inv) inv[(int64_t)t.tree * n_items + rk[u]] = t.start + dst;
                 r1 += sd[u];
                 rv += 1;
             }
