@@ -1288,10 +1288,10 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 if ((rc = split_mm_prepare_rows(h, h->stream2))) { cleanup(); return rc; }
                 F_TRY(hipEventRecord(h->ev_join, h->stream2));
                 side_work = true;
-            } else if (use_mm && order_on && level == 1 && !h->ord_valid && N >= 8192 && n_trees >= 2) {
+            } else if (use_mm && order_on && level == 1 && !h->ord_valid && N >= 8192 && N <= ((int64_t)1 << 22) && n_trees >= 2) {
                 // second level: the rows of the contraction are put in an order in which neighbours are alike (the sides of
                 // the root splits say which are), on the side stream under this level's two_means; from here on `inv` is
-                // kept by row (splitmm.hip, split_mm_order_rows)
+                // kept by row (splitmm.hip, split_mm_order_rows; its counting sort's table is 16 KB per 256 rows: up to 4 M rows)
                 F_TRY(hipEventRecord(h->ev_fork, h->stream));
                 F_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
                 if ((rc = split_mm_order_rows(h, side.p, inv_p, n_trees, h->stream2, &rank_p, &inv_p))) { cleanup(); return rc; }
