@@ -62,7 +62,9 @@ struct QueryParams {
     float delta;
     const float *scores;       // [nq][n_items]  sum_i y_r[i] g_q[i]
     const float *qscale, *qn16, *qe16;   // per query image: indexed by the item id (by-item) or the query number
-    float eacc;
+    float eacc;       // bound of the fp32 accumulation of a filter dot: two chains (128 x 128 form) ...
+    float eacc_big;   // ... one chain: the rows below big_rows went through the 256 x 256 form
+    int64_t big_rows;
 };
 
 __device__ inline uint64_t pq_key(float d, int32_t node)
@@ -238,7 +240,7 @@ template <int BR, int BK, int NS>   // rows of the matrix per workgroup tile, ha
 __global__ __launch_bounds__(MM16_THREADS) void query_scores_kernel(const _Float16 *__restrict__ X16, int64_t n_items, int32_t dpad,
                                                                     const _Float16 *__restrict__ Q16,
                                                                     const int32_t *__restrict__ qrow, int32_t nq,
-                                                                    float *__restrict__ scores)
+                                                                    float *__restrict__ scores, int64_t r_begin /* rows [r_begin, n_items) */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int32_t s_qrow[MM16_TILE];
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(MM16_THREADS) void query_scores_kernel(const _Float
     // so the row tile comes from HBM once and then from that XCD's L2
     const int n_ct = (nq + MM16_TILE - 1) / MM16_TILE;
     const int64_t row_tile = (int64_t)((blockIdx.x >> 3) / n_ct) * 8 + (blockIdx.x & 7);
-    const int64_t r0 = row_tile * BR;
+    const int64_t r0 = r_begin + row_tile * BR;
     const int c0 = (int)((blockIdx.x >> 3) % n_ct) * MM16_TILE;
     if (r0 >= n_items) return;
     if (tid < MM16_TILE) {
@@ -273,6 +275,45 @@ __global__ __launch_bounds__(MM16_THREADS) void query_scores_kernel(const _Float
                     if (q < nq) scores[(int64_t)q * n_items + r] = acc[tb][tn][e];
                 }
         }
+    }
+}
+
+// The same product in 256 x 256 tiles, 16 waves, ONE accumulation chain (mm16.hpp): half the operand bytes delivered to LDS
+// per product, which is what bounds the loop.  Its workgroups take the whole CU, so it covers only as many 256-row tiles as
+// fill the chip in whole rounds (the host picks n_row_tiles); the 128 x 128 form above takes the rows behind them.  The
+// bound on its accumulation is the one-chain EACC (QueryParams::eacc_big).
+template <int BK, int NS>
+__global__ __launch_bounds__(1024) void query_scores_big_kernel(const _Float16 *__restrict__ X16, int64_t n_items, int32_t dpad,
+                                                                const _Float16 *__restrict__ Q16, const int32_t *__restrict__ qrow,
+                                                                int32_t nq, float *__restrict__ scores, int32_t n_row_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int32_t s_qrow[256];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int wm = w >> 2, wn = w & 3;   // the wave's part of the tile: rows wm * 64 .., queries wn * 64 ..
+    const int n_ct = (nq + 255) / 256;
+    const int64_t row_tile = (int64_t)((blockIdx.x >> 3) / n_ct) * 8 + (blockIdx.x & 7);   // XCD b % 8 keeps its row tiles
+    if (row_tile >= n_row_tiles) return;
+    const int64_t r0 = row_tile * 256;   // (+ 255 < n_items: the host covers whole tiles only)
+    const int c0 = (int)((blockIdx.x >> 3) % n_ct) * 256;
+    if (tid < 256) {
+        const int q = c0 + tid < nq ? c0 + tid : nq - 1;
+        s_qrow[tid] = qrow ? qrow[q] : q;
+    }
+    __syncthreads();
+    mm16_f32x16 acc[2][2];
+    mm16_tile_256x256<BK, NS>(X16, Q16, dpad, smem, [&](int rt) { return r0 + rt; }, [&](int rt) { return (int64_t)s_qrow[rt]; }, acc);
+    const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int tb = 0; tb < 2; tb++) {
+        const int64_t r = r0 + wm * 64 + tb * 32 + lr;
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int q = c0 + wn * 64 + tn * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (q < nq) scores[(int64_t)q * n_items + r] = acc[tb][tn][e];
+            }
     }
 }
 
@@ -360,7 +401,7 @@ __global__ __launch_bounds__(Q_THREADS) void query_refine_kernel(QueryParams P)
                 if (sc != 0.f && rx < 0.125f && rq < 0.125f) {
                     // |sum y g - s t x.q| <= (EACC |y| + |d|) |g| + (|y| + |d|) |f|, and s |x| >= |y| - |d|, t |q| >= |g| - |f|:
                     // the cosine taken from the images is within this of the exact one
-                    const float cerr = ((P.eacc + rx) + (1.f + rx) * rq) / ((1.f - rx) * (1.f - rq));
+                    const float cerr = (((id < P.big_rows ? P.eacc_big : P.eacc) + rx) + (1.f + rx) * rq) / ((1.f - rx) * (1.f - rq));
                     df = ang_dist(pp, P.norm2[id], sc_row[id] * sc);
                     dl = 2.02f * cerr + 1e-5f;           // distance = 2 - 2 cos; the canonical norms and ang_dist's own rounding
                 }
@@ -537,7 +578,7 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
         float *scores = (float *)p; p += s_scores;
         P.stat = h->d_stat.p;
         P.X16 = nullptr; P.xscale = nullptr; P.xn16 = P.xe16 = nullptr; P.delta = 0.f;
-        P.scores = nullptr; P.qscale = P.qn16 = P.qe16 = nullptr; P.eacc = 0.f;
+        P.scores = nullptr; P.qscale = P.qn16 = P.qe16 = nullptr; P.eacc = P.eacc_big = 0.f; P.big_rows = 0;
         if (use_filter) {
             const float *xn = (const float *)h->scratch[20].p;
             P.X16 = (const _Float16 *)h->scratch[19].p;
@@ -574,11 +615,32 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
                 } else {
                     P.qn16 = P.xn16; P.qe16 = P.xe16; P.qscale = P.xscale;
                 }
-                const unsigned n_ct = (unsigned)((nb + MM16_TILE - 1) / MM16_TILE), n_rt = (unsigned)((N + 127) / 128);
                 ScopedTimer tf(h, MORNA_T_QUERY_FILTER, 2 * (int64_t)nb * N * h->dpad);   // "bytes" = executed flops
-                HIP_TRY(hipFuncSetAttribute((const void *)query_scores_kernel<128, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, MM16_LDS));
-                hipLaunchKernelGGL((query_scores_kernel<128, 64, 2>), dim3(8u * ((n_rt + 7) / 8) * n_ct), dim3(MM16_THREADS), MM16_LDS,
-                                   h->stream, P.X16, N, h->dpad, q16, qrow, (int32_t)nb, scores);
+                // 256 x 256 tiles for as many 256-row tiles as make whole rounds of the chip (one workgroup per CU), the
+                // 128 x 128 form for the rows behind them (MORNA_QUERY_BIG=0: for all rows)
+                static const bool big_on = !(getenv("MORNA_QUERY_BIG") && atoi(getenv("MORNA_QUERY_BIG")) == 0);
+                int64_t big_tiles = 0;
+                if (big_on && nb >= 512) {
+                    const int64_t n_ct_big = (nb + 255) / 256;
+                    int64_t a = h->n_cus, b = n_ct_big;   // tiles per round of the chip: n_cus / gcd(n_cus, n_ct_big)
+                    while (b) { const int64_t t = a % b; a = b; b = t; }
+                    const int64_t per_round = h->n_cus / a;
+                    big_tiles = (N / 256) / per_round * per_round;
+                }
+                if (big_tiles > 0) {
+                    const unsigned n_ct_big = (unsigned)((nb + 255) / 256);
+                    HIP_TRY(hipFuncSetAttribute((const void *)query_scores_big_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 256 * 4));
+                    hipLaunchKernelGGL((query_scores_big_kernel<64, 2>), dim3(8u * (unsigned)((big_tiles + 7) / 8) * n_ct_big), dim3(1024), 128 * 256 * 4,
+                                       h->stream, P.X16, N, h->dpad, q16, qrow, (int32_t)nb, scores, (int32_t)big_tiles);
+                    P.big_rows = big_tiles * 256;
+                    P.eacc_big = (4.f * (float)h->dpad + 2.f) * 5.9604645e-8f + 4.1e-6f;   // EACC for ONE chain of dpad products
+                }
+                if (P.big_rows < N) {
+                    const unsigned n_ct = (unsigned)((nb + MM16_TILE - 1) / MM16_TILE), n_rt = (unsigned)((N - P.big_rows + 127) / 128);
+                    HIP_TRY(hipFuncSetAttribute((const void *)query_scores_kernel<128, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, MM16_LDS));
+                    hipLaunchKernelGGL((query_scores_kernel<128, 64, 2>), dim3(8u * ((n_rt + 7) / 8) * n_ct), dim3(MM16_THREADS), MM16_LDS,
+                                       h->stream, P.X16, N, h->dpad, q16, qrow, (int32_t)nb, scores, P.big_rows);
+                }
                 P.scores = scores;
             }
             // beside the contraction (matrix cores, LDS) the traversal is a latency chain on one wave per query: it

@@ -110,6 +110,12 @@ def test_c3_queries_distances_and_recall_vs_exact(c3):
         # ranked by (2 - 2 cos, id) as annoy does; the square root that is reported can make two different keys
         # print equal: ascending distances, distinct ids
         assert (np.diff(d[qi]) >= 0).all() and len(set(ids[qi].tolist())) == K3
+    # an answer does not depend on which queries share its batch: 1000 at once go through the 256 x 256 form of the filter
+    # contraction (whole rounds of the chip) + the 128 x 128 form for the rows behind, 400 at once through the 128 x 128
+    # form alone, 40 at once through the per-candidate form -- three different filters, one result
+    for part in (400, 40):
+        pi, pd, pc = a.get_nns_by_item_batch(items[:part], K3, SEARCH_K)
+        assert pi.tolist() == ids[:part].tolist() and pd.tobytes() == d[:part].tobytes() and pc.tolist() == cnt[:part].tolist(), part
     eids, ed, ecnt = a.exact_search_batch(X[items].astype(np.float64), K3)
     assert (ecnt == K3).all()
     recall = np.mean([len(set(ids[i].tolist()) & set(eids[i].tolist())) / float(K3) for i in range(Q3)])
