@@ -249,7 +249,7 @@ int split_mm_convert_rows(morna_index *h, const float *src, int64_t rows, _Float
                           float *inv_scale, hipStream_t stream);
 int split_mm_order_rows(morna_index *h, const uint8_t *side, const int32_t *inv_by_item, int32_t n_trees, hipStream_t stream,
                         const int32_t **rank_out, int32_t **inv_out);
-int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, const float *hp_level,
+int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, int32_t n_slots, const float *hp_level,
                    const int32_t *perm, const int32_t *inv, uint32_t seed, uint8_t *side, int32_t *ones);
 // packed_dev (device memory, or null): [nq][2k] int32 message of the row-sharded search -- ids + id_offset, distance bits
 int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int32_t *items_host, int64_t nq, int32_t k,

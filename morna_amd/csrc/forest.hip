@@ -1272,8 +1272,17 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             // contraction on the matrix cores (splitmm.hip): its cost grows with the nodes per tree (every row
             // meets every hyperplane), the chunk form's does not -- they meet near 64 nodes per tree.
             // MORNA_SPLIT_MM=0 turns it off (row-window / chunk forms as before).
-            const bool use_mm = mm_on && attempt == 0 && max_per_tree >= 1 && max_per_tree <= 32 &&
-                                rows * 2 >= (int64_t)n_trees * N;
+            // Once the rows of the contraction are ordered and the level has enough tasks for the per-tile lists
+            // (splitmm.hip), a row tile meets only the tasks that hold one of its rows, and the cost follows the (tile,
+            // task) pairs that exist: then deeper levels (up to 256 nodes per tree) and the retries of a level go there too,
+            // as does any set of tasks whose all-pairs product in 128 x 128 tiles is cheaper than streaming the rows once
+            // per tree (measured at D = 3000: 0.13 us per tile pair, 0.47 ns per row of the chunk form, both ~ dpad).
+            // On a shard of 200k x 3000 the chunk form took 28 of the split's 34 ms, retries and levels 7+.
+            static const bool lists_env = !(getenv("MORNA_SPLIT_LISTS") && atoi(getenv("MORNA_SPLIT_LISTS")) == 0);
+            const bool mm_lists = lists_env && h->ord_valid && A >= 512 && max_per_tree <= 256;
+            const double mm_dense_us = (double)((N + 127) / 128) * (double)((A + 127) / 128) * 0.13, chunk_us = (double)rows * 0.47e-3;
+            const bool use_mm = mm_on && max_per_tree >= 1 &&
+                                (mm_lists || (max_per_tree <= 32 && (attempt == 0 ? rows * 2 >= (int64_t)n_trees * N : mm_dense_us < chunk_us)));
             if ((rc = upload_tasks(tasks))) { cleanup(); return rc; }
             // (d_ones is zeroed by the two_means kernel of the attempt, task by task: a hipMemsetAsync costs ~15 us of
             // idle device around its few microseconds)
@@ -1362,7 +1371,7 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
             if (side_work) F_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
             if (use_mm) {
                 ScopedTimer tm(h, MORNA_T_SPLIT, 4 * (int64_t)D * (rows + A));
-                if ((rc = split_mm_level(h, d_tasks.p, A, hp_level, work.p, inv_p, seed, side.p, d_ones.p))) {
+                if ((rc = split_mm_level(h, d_tasks.p, A, S, hp_level, work.p, inv_p, seed, side.p, d_ones.p))) {
                     cleanup();
                     return rc;
                 }

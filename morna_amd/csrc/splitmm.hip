@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256) void rows_to_half_kernel(const float *__restri
 }
 
 // ---- the contraction with the side decision fused into its epilogue --------------------------------
-#define SM_OPEN 1536             // open pairs a tile keeps in LDS (12 KB; ~500 expected of 16384 at the root level)
+#define SM_OPEN 1408             // open pairs a tile keeps in LDS (11 KB; ~500 expected of 16384 at the root level; the 128 x 128 form must stay
+                                 // within 16 KB of static LDS beside its 64 KB of slabs for two workgroups to share a CU)
 
 // BIG = false: 128 rows x 128 hyperplanes per workgroup, 8 waves, two accumulation chains; two workgroups per CU.
 // BIG = true : 256 x 256, 16 waves, one chain (mm16.hpp): half the operand bytes delivered to LDS per product -- the
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(BIG ? 1024 : 512) void split_mm_kernel(
     // a time (BIG: the two halves of the hyperplane tile in turn)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *Cs = (float *)smem;
-    __shared__ int s_ones[COLS], s_tree[COLS], s_start[COLS], s_end[COLS], s_task[COLS];
+    __shared__ int s_ones[COLS], s_tree[COLS], s_start[COLS], s_end[COLS], s_task[COLS], s_slot[COLS];
     __shared__ float s_hn[COLS], s_he[COLS];
     __shared__ int2 s_open[SM_OPEN];   // pairs this tile's filter left open
     __shared__ int s_nopen;
@@ -159,11 +160,12 @@ __global__ __launch_bounds__(BIG ? 1024 : 512) void split_mm_kernel(
         s_ones[tid] = 0;
         if (tid == 0) s_nopen = 0;
         s_task[tid] = col;
+        s_slot[tid] = t.slot;   // row of the level's hyperplane image (= the task's number on a first attempt)
         s_tree[tid] = t.tree;
         s_start[tid] = t.start;
         s_end[tid] = t.start + t.count;
-        s_hn[tid] = hn[col];
-        s_he[tid] = he[col];
+        s_hn[tid] = hn[t.slot];
+        s_he[tid] = he[t.slot];
     }
     __syncthreads();   // the delivery addresses below come from s_task
     // the contraction (mm16.hpp): hyperplanes are the A side (m) and the rows the B side (n), so the result has a
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(BIG ? 1024 : 512) void split_mm_kernel(
         const int64_t r = r0 + rt < n_items ? r0 + rt : n_items - 1;
         return item_at ? (int64_t)item_at[r] : r;   // (a lane asks once: the delivery addresses are kept in registers)
     };
-    auto a_row = [&](int rt) { return (int64_t)s_task[rt]; };
+    auto a_row = [&](int rt) { return (int64_t)s_slot[rt]; };
     if constexpr (BIG) mm16_tile_256x256<64, 2>(X16, H16, dpad, smem, b_row, a_row, acc);   // (4 stages of 32 halfs, three deliveries in flight: 0.62 / 0.73 ms against 0.57 / 0.66 at C3)
     else mm16_tile<128, 64, 2>(X16, H16, dpad, smem, b_row, a_row, acc);
     const int lr = lane & 31, lh = lane >> 5;
@@ -563,7 +565,9 @@ int split_mm_convert_rows(morna_index *h, const float *src, int64_t rows, _Float
     return MORNA_OK;
 }
 
-int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, const float *hp_level,
+// n_slots: hyperplanes of the level (hp_level[slot]); the tasks are all of them in order (a first attempt: slot = task
+// number) or the retried ones among them
+int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, int32_t n_slots, const float *hp_level,
                    const int32_t *perm, const int32_t *inv, uint32_t seed, uint8_t *side, int32_t *ones)
 {
     const int64_t N = h->n_items;
@@ -581,14 +585,14 @@ int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, co
         set_error("split_mm_level: %lld x %d (row, tree) pairs exceed the open-pair list", (long long)N, h->n_trees);
         return MORNA_E_INVALID;
     }
-    MORNA_TRY(h16.alloc((size_t)n_tasks * h->dpad));
-    MORNA_TRY(hn.alloc((size_t)n_tasks * 2));   // norms, then rounding-error norms
+    MORNA_TRY(h16.alloc((size_t)n_slots * h->dpad));
+    MORNA_TRY(hn.alloc((size_t)n_slots * 2));   // norms, then rounding-error norms
     MORNA_TRY(ambuf.alloc(16 + cap * sizeof(int2)));
     unsigned int *amb_count = (unsigned int *)ambuf.p;
     int2 *amb = (int2 *)(ambuf.p + 16);
     // the open-pair counter is reset by the kernel that converts the level's hyperplanes (same stream, just before)
-    hipLaunchKernelGGL(rows_to_half_kernel, dim3((unsigned)((n_tasks + 3) / 4)), dim3(256), 0, h->stream, hp_level,
-                       (int64_t)n_tasks, h->dpad, h16.p, hn.p, hn.p + n_tasks, (float *)nullptr, amb_count);
+    hipLaunchKernelGGL(rows_to_half_kernel, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, h->stream, hp_level,
+                       (int64_t)n_slots, h->dpad, h16.p, hn.p, hn.p + n_slots, (float *)nullptr, amb_count);
     // 256 x 256 tiles once the level has hyperplane tiles enough for them to fill the chip in even rounds (MORNA_SPLIT_BIG=0:
     // the 128 x 128 form everywhere)
     static const bool big_on = !(getenv("MORNA_SPLIT_BIG") && atoi(getenv("MORNA_SPLIT_BIG")) == 0);
@@ -616,14 +620,14 @@ int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, co
         const float eps1 = (4.f * (float)h->dpad + 2.f) * 5.9604645e-8f + 4.1e-6f;   // EACC for ONE chain of dpad products
         HIP_TRY(hipFuncSetAttribute((const void *)split_mm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 256 * 4));
         hipLaunchKernelGGL(split_mm_kernel<true>, dim3(8u * ((n_rt + 7) / 8) * n_ct), dim3(1024), 128 * 256 * 4, h->stream, rows16, rows_n,
-                           rows_e, N, h->dpad, h16.p, hn.p, hn.p + n_tasks, n_tasks, d_tasks, inv, item_at, eps1, side, ones,
+                           rows_e, N, h->dpad, h16.p, hn.p, hn.p + n_slots, n_tasks, d_tasks, inv, item_at, eps1, side, ones,
                            amb_count, amb, (unsigned int)cap, col_list, col_count, col_first);
     } else {
         const unsigned n_rt = (unsigned)((N + 127) / 128), n_ct = (unsigned)((n_tasks + 127) / 128);
         static_assert(MM16_LDS == 128 * 128 * 4, "the slabs and the result tile share the dynamic LDS");
         HIP_TRY(hipFuncSetAttribute((const void *)split_mm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 4));
         hipLaunchKernelGGL(split_mm_kernel<false>, dim3(8u * ((n_rt + 7) / 8) * n_ct), dim3(512), 128 * 128 * 4, h->stream, rows16, rows_n,
-                           rows_e, N, h->dpad, h16.p, hn.p, hn.p + n_tasks, n_tasks, d_tasks, inv, item_at, sm_eps(h->dpad), side,
+                           rows_e, N, h->dpad, h16.p, hn.p, hn.p + n_slots, n_tasks, d_tasks, inv, item_at, sm_eps(h->dpad), side,
                            ones, amb_count, amb, (unsigned int)cap, (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr);
     }
     hipLaunchKernelGGL(split_amb_kernel, dim3((unsigned)(4 * h->n_cus)), dim3(256), 0, h->stream, h->X.p, N, h->dpad, d_tasks,
