@@ -5,7 +5,10 @@
 // restated in oracle/annoy_oracle.c mode 1 and SURVEY.md section 2.1).
 //
 // All n_trees trees advance one level per round.  A tree is a permutation of the
-// item ids (perm[tree][N]); a node is a contiguous segment of it.  Per level:
+// item ids (perm[tree][N]); a node is a contiguous segment of it.  During a build the
+// permutations live in a work buffer of two images per tree, [tree][2][N]: a node of depth
+// L has its items in image L & 1 (TASK_ITEMS_AT), a partition writes its children into the
+// other image, and the finished leaves are gathered into perm at the end.  Per level:
 //   two_means_wave_kernel  one WAVE per split node, centroids / current row / next
 //                     row in registers: 200 sequential centroid updates, the row of
 //                     step l+1 in flight during step l (the Kiss32 stream does not
@@ -16,7 +19,9 @@
 //                     per node) for rows too long for the register file.
 //   (splitmm.hip)     the sides of the whole level as one fp16 MFMA product that filters,
 //                     exact fp32 dots for the pairs it cannot decide -- the form that runs
-//                     while a tree has at most 32 split nodes.  Otherwise, and for retries:
+//                     while a tree has at most 32 split nodes, and, once the rows of the
+//                     contraction are ordered and a row tile is multiplied with its own list
+//                     of tasks, up to 256 per tree and for retries.  Otherwise:
 //   split_kernel      every row of every split node is dotted (wavefront dot product,
 //                     hyperplane resident in LDS) against its node's hyperplane, one
 //                     workgroup per 64 positions of a node; launch order sorted by row
@@ -27,8 +32,11 @@
 //   post_counts_kernel  the level's right-side counts into a page-locked mailbox the host polls
 //   (host)            annoy's 3-attempt / 0.95 imbalance rule on the counts
 //   fallback_kernel   random sides for nodes still above 0.99
-//   partition_kernel  stable partition of each segment by side; keeps inv[tree][item], the item's position in the tree,
+//   partition_kernel  stable partition of each segment by side, from one image of the tree into the other; keeps
+//                     inv[tree][row], the position in the tree of the item a row of the contraction stands for,
 //                     current (what the matrix-core split finds a row's node with)
+//   pull_tasks_kernel / gather_leaves_kernel  task lists and node tables out of page-locked host memory; the leaves
+//                     into perm when the build ends
 // Node ids are handed out breadth-first, children of the i-th split node of a
 // level get consecutive ids, exactly as oracle mode 1 does.
 #include <algorithm>
