@@ -104,6 +104,14 @@ def main():
             pair = pair[node_of.ravel() >= 0]
             act = np.unique(pair)
             per_tile = np.bincount(act // S, minlength=n_tiles)
+            if name.startswith("L1:tree0..11") or name == "natural":
+                # what pruning the (tile, task) pairs with few rows would leave: rows of a pair, sorted pair ids
+                upair, cnt_rows = np.unique(pair, return_counts=True)
+                for thr in (1, 2, 4, 8):
+                    keep = upair[cnt_rows > thr]
+                    pt = np.bincount(keep // S, minlength=n_tiles)
+                    lvl.setdefault("prune", {})["%s thr%d" % (name, thr)] = {
+                        "blocks_256": int(np.sum((pt + 255) // 256)), "pairs_to_exact_pass": int(cnt_rows[cnt_rows <= thr].sum())}
             lvl["orders"][name] = {
                 "active_pairs": int(len(act)), "of_dense": float(len(act) / (n_tiles * S)),
                 "blocks_256": int(np.sum((per_tile + 255) // 256)), "blocks_128": int(np.sum((per_tile + 127) // 128)),
