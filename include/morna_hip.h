@@ -112,6 +112,23 @@ int morna_stage_lines(morna_index *h, const morna_lines *L);
 int morna_lines_save(const morna_lines *L, const char *path, const int64_t *tag);
 int morna_lines_load(const char *path, int64_t *tag_out, morna_lines **out);
 int morna_lines_free(morna_lines *L);
+/*
+ * Row shards of ONE parsed data set (the reference has no such path).  The parse is the global pass of
+ * add_junction -- threshold on a line's whole sample list, cumulative frequency, idf = log(sample_count / freq) with the
+ * GLOBAL sample count (morna.py:357-374), first-seen internal ids over the whole file (morna.py:377-382).  Shard `rank`
+ * of `world` owns the global ids [rank * ceil(N / world), (rank + 1) * ceil(N / world)) and gets the lines restricted to
+ * the entries of its items, in file order, ids renumbered from 0 (lines left without an entry are dropped; the frequency
+ * table stays whole).  The matrices built from the shards, stacked by rank, are the matrix of the whole index bit for bit:
+ * a cell's terms and their order (morna.py:376-388) do not depend on the other rows.
+ *   morna_lines_shard_info  info[4] = {rank, world, id_offset (global id of local id 0), n_items of the whole data set}
+ *   morna_lines_from_arrays the same object from arrays the caller tokenised itself (what morna_stage_junctions takes,
+ *                           plus ext_ids[n_items], the external sample id of every internal id, and the sample count)
+ */
+int morna_lines_shard(const morna_lines *L, int32_t rank, int32_t world, morna_lines **out);
+int morna_lines_shard_info(const morna_lines *L, int64_t *info);
+int morna_lines_from_arrays(const uint8_t *key_bytes, const int64_t *key_off, int64_t J, const int64_t *row_ptr,
+                            const int32_t *item_ids, const int32_t *cov, const double *idf, const int64_t *ext_ids,
+                            int64_t n_items, int64_t sample_count, morna_lines **out);
 /* Benchmark / test utility (no counterpart in the reference): J lines written as an intropolis text file, gzipped when
  * the path ends in ".gz": key words, "+", "GT", "AG", the sample list, the coverage list, tab separated. */
 int morna_write_intropolis(const char *path, const uint8_t *key_bytes, const int64_t *key_off, int64_t J, const int64_t *row_ptr,

@@ -46,6 +46,9 @@ SIGNATURES = {
     "morna_lines_save": (C.c_int, [_p, C.c_char_p, _p]),
     "morna_lines_load": (C.c_int, [C.c_char_p, _p, C.POINTER(_p)]),
     "morna_lines_free": (C.c_int, [_p]),
+    "morna_lines_shard": (C.c_int, [_p, _i32, _i32, C.POINTER(_p)]),
+    "morna_lines_shard_info": (C.c_int, [_p, _p]),
+    "morna_lines_from_arrays": (C.c_int, [_p, _p, _i64, _p, _p, _p, _p, _p, _i64, _i64, C.POINTER(_p)]),
     "morna_write_intropolis": (C.c_int, [C.c_char_p, _p, _p, _i64, _p, _p, _p]),
     "morna_merge_topk": (C.c_int, [_p, _p, _i32, _i64, _i32, _i32, _p, _p, _p]),
     "morna_get_nns_by_vector_packed": (C.c_int, [_p, _p, _i64, _i32, _i32, _i64, _p]),

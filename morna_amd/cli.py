@@ -84,6 +84,11 @@ def build_parser():
     index_parser.add_argument('--cache', metavar='<file>', type=str, required=False, default=None,
                               help='binary pre-tokenised cache of the intropolis file: reused when it matches the '
                                    'file, sample count and threshold, (re)written otherwise')
+    index_parser.add_argument('--shards', metavar='<int>', type=int, required=False, default=1,
+                              help='cut the samples into this many contiguous row shards, each with its own matrix + '
+                                   'forest file (one per GPU); global idf and internal ids, so the shards together are '
+                                   'the index.  Under torchrun with WORLD_SIZE equal to --shards every rank builds its '
+                                   'own shard on its own GPU; otherwise one process builds them one after the other')
     add_search_parameters(search_parser)
     return parser
 
@@ -93,10 +98,14 @@ def main(argv=None, stdin=None, stdout=None):
     stdin = stdin or sys.stdin
     stdout = stdout or sys.stdout
     if args.subparser_name == 'index':
+        import os
         from .index import go_index
+        rank, device = None, args.device
+        if args.shards > 1 and int(os.environ.get("WORLD_SIZE", "1")) == args.shards:   # one process per GPU
+            rank, device = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
         go_index(args.intropolis, args.basename, args.features, args.n_trees, args.sample_count,
-                 args.sample_threshold, args.buffer_size, args.verbose, args.metafile, device=args.device,
-                 native=not args.python_parse, cache=args.cache)
+                 args.sample_threshold, args.buffer_size, args.verbose, args.metafile, device=device,
+                 native=not args.python_parse, cache=args.cache, shards=args.shards, rank=rank)
         return 0
     if args.subparser_name != 'search':
         build_parser().print_help()

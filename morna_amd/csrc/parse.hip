@@ -37,6 +37,8 @@ struct morna_lines {
     std::vector<std::string> freq_keys;                 // insertion order, for the accessor
     std::vector<int64_t> freq_vals;
     int64_t sample_count = 0, skipped = 0, lines_read = 0;
+    // a row shard cut by morna_lines_shard: the ids above are LOCAL (global id - id_offset); of a whole parse: 0 / 1 / 0 / n_items
+    int64_t shard_rank = 0, shard_world = 1, id_offset = 0, n_items_global = -1;
 };
 
 namespace {
@@ -218,6 +220,24 @@ struct BlockPipeline {
     std::vector<std::thread> threads;
     size_t max_in_flight = 32;
 
+    // 0 / MORNA_E_IO (a damaged or truncated .gz: the reference's gzip.open raises there) / MORNA_E_INVALID (an exception
+    // in a thread, e.g. bad_alloc): set by whichever thread hits it, read by the caller after stop()
+    std::atomic<int> fatal{0};
+    std::string fatal_msg;          // written once, under mu, before `fatal` is set
+
+    void fail(int code, const std::string &msg)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!fatal.load()) {
+            fatal_msg = msg;
+            fatal = code;
+        }
+        eof = true;
+        cv_work.notify_all();
+        cv_done.notify_all();
+        cv_room.notify_all();
+    }
+
     bool read_block(std::string &carry, ParsedBlock &B, int64_t &line_no)
     {
         // whole lines only: what follows the last newline is carried into the next block
@@ -230,7 +250,18 @@ struct BlockPipeline {
             t.resize(old + BLOCK_BYTES);
             const int got = gzread(f, &t[old], (unsigned)BLOCK_BYTES);
             t.resize(old + (got > 0 ? (size_t)got : 0));
-            if (got <= 0) break;                                    // end of file (or a read error: what was read is used)
+            if (got < (int)BLOCK_BYTES) {
+                // a short read is the end of the file -- or of what can be inflated of it: zlib reports a stream that
+                // stops early as Z_BUF_ERROR and damaged data as Z_DATA_ERROR, with the bytes before it delivered
+                int errnum = Z_OK;
+                const char *why = gzerror(f, &errnum);
+                if (got < 0 || (errnum != Z_OK && errnum != Z_STREAM_END)) {
+                    read_error = true;
+                    read_error_msg = why ? why : "read error";
+                    return false;
+                }
+            }
+            if (got <= 0) break;                                    // end of file
             const size_t nl = t.rfind('\n');
             if (nl != std::string::npos) {
                 carry.assign(t, nl + 1, std::string::npos);
@@ -243,6 +274,8 @@ struct BlockPipeline {
         if (t.back() != '\n') line_no++;                            // the file's last line without a terminator
         return true;
     }
+    bool read_error = false;        // reader's side only (one thread), folded into `fatal` by whoever reads
+    std::string read_error_msg;
 
     void start(const char *path_unused, bool count, int workers)
     {
@@ -251,38 +284,51 @@ struct BlockPipeline {
         n_workers = workers;
         if (n_workers <= 1) return;
         threads.emplace_back([this] {   // the reader: inflation
-            std::string carry;
-            int64_t line_no = 1;
-            for (;;) {
-                std::unique_ptr<ParsedBlock> B(new ParsedBlock());
-                const bool any = read_block(carry, *B, line_no);
-                std::unique_lock<std::mutex> lk(mu);
-                if (!any) {
-                    eof = true;
-                    cv_work.notify_all();
-                    cv_done.notify_all();
-                    return;
+            try {
+                std::string carry;
+                int64_t line_no = 1;
+                for (;;) {
+                    std::unique_ptr<ParsedBlock> B(new ParsedBlock());
+                    const bool any = read_block(carry, *B, line_no);
+                    if (read_error) {
+                        fail(MORNA_E_IO, read_error_msg);
+                        return;
+                    }
+                    std::unique_lock<std::mutex> lk(mu);
+                    if (!any) {
+                        eof = true;
+                        cv_work.notify_all();
+                        cv_done.notify_all();
+                        return;
+                    }
+                    cv_room.wait(lk, [this] { return blocks.size() < max_in_flight || fatal.load(); });
+                    if (fatal.load()) return;
+                    blocks.push_back(std::move(B));
+                    cv_work.notify_one();
                 }
-                cv_room.wait(lk, [this] { return blocks.size() < max_in_flight; });
-                blocks.push_back(std::move(B));
-                cv_work.notify_one();
+            } catch (const std::exception &e) {
+                fail(MORNA_E_INVALID, e.what());
             }
         });
         for (int w = 0; w < n_workers - 1; w++)
             threads.emplace_back([this] {   // the tokenisers
-                for (;;) {
-                    ParsedBlock *B = nullptr;
-                    {
-                        std::unique_lock<std::mutex> lk(mu);
-                        cv_work.wait(lk, [this] { return next_to_parse < blocks.size() || eof; });
-                        if (next_to_parse >= blocks.size()) return;   // eof and nothing left
-                        B = blocks[next_to_parse++].get();
+                try {
+                    for (;;) {
+                        ParsedBlock *B = nullptr;
+                        {
+                            std::unique_lock<std::mutex> lk(mu);
+                            cv_work.wait(lk, [this] { return next_to_parse < blocks.size() || eof; });
+                            if (fatal.load() || next_to_parse >= blocks.size()) return;   // eof and nothing left
+                            B = blocks[next_to_parse++].get();
+                        }
+                        parse_block(*B, count_only);
+                        {
+                            std::lock_guard<std::mutex> lk(mu);
+                            cv_done.notify_all();
+                        }
                     }
-                    parse_block(*B, count_only);
-                    {
-                        std::lock_guard<std::mutex> lk(mu);
-                        cv_done.notify_all();
-                    }
+                } catch (const std::exception &e) {
+                    fail(MORNA_E_INVALID, e.what());
                 }
             });
     }
@@ -293,19 +339,31 @@ struct BlockPipeline {
     std::unique_ptr<ParsedBlock> next_block()
     {
         if (n_workers <= 1) {
+            if (fatal.load()) return nullptr;
             std::unique_ptr<ParsedBlock> B(new ParsedBlock());
-            if (!read_block(carry1, *B, line1)) return nullptr;
+            const bool any = read_block(carry1, *B, line1);
+            if (read_error) {
+                fail(MORNA_E_IO, read_error_msg);
+                return nullptr;
+            }
+            if (!any) return nullptr;
             parse_block(*B, count_only);
             return B;
         }
         std::unique_lock<std::mutex> lk(mu);
-        cv_done.wait(lk, [this] { return (!blocks.empty() && blocks.front()->done) || (eof && blocks.empty()); });
-        if (blocks.empty()) return nullptr;
+        cv_done.wait(lk, [this] { return fatal.load() || (!blocks.empty() && blocks.front()->done) || (eof && blocks.empty()); });
+        if (fatal.load() || blocks.empty()) return nullptr;
         std::unique_ptr<ParsedBlock> B = std::move(blocks.front());
         blocks.pop_front();
         next_to_parse--;   // indices shift with the pop; the front block was taken by a worker long ago
         cv_room.notify_one();
         return B;
+    }
+
+    // the caller gives up (an exception on its side): the threads leave at their next look at the queue
+    void abandon()
+    {
+        if (!threads.empty() && !fatal.load()) fail(MORNA_E_INVALID, "abandoned");
     }
 
     void stop()
@@ -327,17 +385,31 @@ static int parse_threads()
     return (int)std::min<unsigned>(std::max<unsigned>(hc, 1u), 12u);
 }
 
-int morna_parse_intropolis(const char *path, int64_t sample_count, int64_t sample_threshold, morna_lines **out)
+// stop the threads, close the file and fold what the pipeline or zlib reported into a return code
+static int finish_pipeline(BlockPipeline &P, const char *path, int rc)
 {
-    if (!path || !out) {
-        set_error("parse_intropolis: null argument");
-        return MORNA_E_INVALID;
+    P.stop();
+    const int zrc = P.f ? gzclose(P.f) : Z_OK;
+    P.f = nullptr;
+    if (P.fatal.load()) {
+        if (P.fatal.load() == MORNA_E_IO) set_error("%s: %s (truncated or damaged gzip stream)", path, P.fatal_msg.c_str());
+        else set_error("parse_intropolis: %s", P.fatal_msg.c_str());
+        return P.fatal.load();
     }
-    *out = nullptr;
+    if (rc == MORNA_OK && zrc != Z_OK) {
+        set_error("%s: gzclose reports error %d (truncated or damaged gzip stream)", path, zrc);
+        return MORNA_E_IO;
+    }
+    return rc;
+}
+
+static int parse_intropolis_impl(const char *path, int64_t sample_count, int64_t sample_threshold, BlockPipeline &PC,
+                                 BlockPipeline &P, std::unique_ptr<morna_lines> &result)
+{
     const int workers = parse_threads();
     if (sample_count <= 0) {
         // count_samples (morna.py:789-822): distinct sample-id STRINGS of column -2
-        BlockPipeline P;
+        BlockPipeline &P = PC;
         P.f = gzopen(path, "rb");   // transparently reads plain text too
         if (!P.f) {
             set_error("Unable to open %s", path);
@@ -358,12 +430,10 @@ int morna_parse_intropolis(const char *path, int64_t sample_count, int64_t sampl
             if (rc == MORNA_OK)
                 for (std::string &id : B->ids_seen) seen.insert(std::move(id));
         }
-        P.stop();
-        gzclose(P.f);
+        rc = finish_pipeline(P, path, rc);
         if (rc != MORNA_OK) return rc;
         sample_count = (int64_t)seen.size();
     }
-    BlockPipeline P;
     P.f = gzopen(path, "rb");
     if (!P.f) {
         set_error("Unable to open %s", path);
@@ -371,7 +441,8 @@ int morna_parse_intropolis(const char *path, int64_t sample_count, int64_t sampl
     }
     gzbuffer(P.f, 1 << 20);
     P.start(path, false, workers);
-    morna_lines *L = new morna_lines();
+    result.reset(new morna_lines());
+    morna_lines *L = result.get();
     L->sample_count = sample_count;
     // internal_id_map (morna.py:377-382): a table indexed by the sample id while the ids are small non-negative numbers
     // (1e8 look-ups are the merge's cost), a hash map for the others
@@ -447,16 +518,38 @@ int morna_parse_intropolis(const char *path, int64_t sample_count, int64_t sampl
         }
         if (rc == MORNA_OK) lineno = B->first_line + (int64_t)B->lines.size() - 1;
     }
-    P.stop();
-    gzclose(P.f);
-    if (rc != MORNA_OK) {
-        delete L;
-        return rc;
-    }
+    rc = finish_pipeline(P, path, rc);
+    if (rc != MORNA_OK) return rc;
     L->lines_read = lineno;
     L->freq_vals.reserve(L->freq_keys.size());
     for (const std::string &k : L->freq_keys) L->freq_vals.push_back(L->freq[k]);
-    *out = L;
+    return MORNA_OK;
+}
+
+int morna_parse_intropolis(const char *path, int64_t sample_count, int64_t sample_threshold, morna_lines **out)
+{
+    if (!path || !out) {
+        set_error("parse_intropolis: null argument");
+        return MORNA_E_INVALID;
+    }
+    *out = nullptr;
+    BlockPipeline count_pass, main_pass;
+    std::unique_ptr<morna_lines> L;
+    int rc;
+    try {
+        rc = parse_intropolis_impl(path, sample_count, sample_threshold, count_pass, main_pass, L);
+    } catch (const std::exception &e) {   // bad_alloc in the merge: nothing may cross the C ABI, no thread may outlive the call
+        set_error("parse_intropolis: %s", e.what());
+        rc = MORNA_E_INVALID;
+    }
+    for (BlockPipeline *P : {&count_pass, &main_pass}) {   // whatever path was taken: threads joined, file closed
+        P->abandon();
+        P->stop();
+        if (P->f) gzclose(P->f);
+        P->f = nullptr;
+    }
+    if (rc != MORNA_OK) return rc;
+    *out = L.release();
     return MORNA_OK;
 }
 
@@ -655,6 +748,145 @@ int morna_write_intropolis(const char *path, const uint8_t *key_bytes, const int
     if (!ok) {
         set_error("short write to %s", path);
         return MORNA_E_IO;
+    }
+    return MORNA_OK;
+}
+
+// ---- row shards of ONE parsed data set -----------------------------------------------------------
+// The global pass above has done everything that is global by definition: the threshold on a line's whole sample list,
+// the cumulative frequency and idf = log(sample_count / freq) with the GLOBAL sample count (morna.py:357-374), first-seen
+// internal ids over the whole file (morna.py:377-382).  Shard `rank` of `world` owns the global ids
+// [rank * ceil(N / world), (rank + 1) * ceil(N / world)) and receives, in file order, the lines restricted to the
+// entries of its items, ids renumbered from 0.  A cell of the matrix is the sum, in file order, of the entries of ITS
+// sample in the lines of ITS column (morna.py:376-388): restricting the lines to a row range changes neither the terms
+// of a cell nor their order, so the shard matrices stacked by rank ARE the matrix of the whole index, bit for bit.
+// Lines that lose every entry are dropped (they touch no cell of the shard).  The frequency table stays global.
+int morna_lines_shard(const morna_lines *L, int32_t rank, int32_t world, morna_lines **out)
+{
+    if (!L || !out || world <= 0 || rank < 0 || rank >= world) {
+        set_error("lines_shard: need 0 <= rank < world");
+        return MORNA_E_INVALID;
+    }
+    *out = nullptr;
+    if (L->shard_world != 1) {
+        set_error("lines_shard: the lines are a shard already (cut the whole parse)");
+        return MORNA_E_STATE;
+    }
+    try {
+        const int64_t N = (int64_t)L->ext_ids.size(), per = (N + world - 1) / world;
+        const int64_t lo = std::min<int64_t>(N, per * rank), hi = std::min<int64_t>(N, lo + per);
+        const int64_t J = (int64_t)L->idf.size();
+        std::unique_ptr<morna_lines> S(new morna_lines());
+        // sizes first (one pass), then the copy: no reallocation of the big arrays
+        int64_t nnz = 0, nl = 0, kb = 0;
+        for (int64_t j = 0; j < J; j++) {
+            int64_t c = 0;
+            for (int64_t t = L->row_ptr[(size_t)j]; t < L->row_ptr[(size_t)j + 1]; t++) {
+                const int64_t id = L->item_ids[(size_t)t];
+                c += (id >= lo && id < hi) ? 1 : 0;
+            }
+            if (c) {
+                nnz += c;
+                nl++;
+                kb += L->key_off[(size_t)j + 1] - L->key_off[(size_t)j];
+            }
+        }
+        S->item_ids.resize((size_t)nnz);
+        S->cov.resize((size_t)nnz);
+        S->idf.reserve((size_t)nl);
+        S->key_off.reserve((size_t)nl + 1);
+        S->row_ptr.reserve((size_t)nl + 1);
+        S->key_bytes.reserve((size_t)kb);
+        int64_t at = 0;
+        for (int64_t j = 0; j < J; j++) {
+            const int64_t at0 = at;
+            for (int64_t t = L->row_ptr[(size_t)j]; t < L->row_ptr[(size_t)j + 1]; t++) {
+                const int64_t id = L->item_ids[(size_t)t];
+                if (id >= lo && id < hi) {
+                    S->item_ids[(size_t)at] = (int32_t)(id - lo);
+                    S->cov[(size_t)at] = L->cov[(size_t)t];
+                    at++;
+                }
+            }
+            if (at == at0) continue;
+            S->row_ptr.push_back(at);
+            S->idf.push_back(L->idf[(size_t)j]);
+            S->key_bytes.insert(S->key_bytes.end(), L->key_bytes.begin() + L->key_off[(size_t)j],
+                                L->key_bytes.begin() + L->key_off[(size_t)j + 1]);
+            S->key_off.push_back((int64_t)S->key_bytes.size());
+        }
+        S->ext_ids.assign(L->ext_ids.begin() + lo, L->ext_ids.begin() + hi);
+        S->freq_keys = L->freq_keys;
+        S->freq_vals = L->freq_vals;
+        S->sample_count = L->sample_count;
+        S->skipped = L->skipped;
+        S->lines_read = L->lines_read;
+        S->shard_rank = rank;
+        S->shard_world = world;
+        S->id_offset = lo;
+        S->n_items_global = N;
+        *out = S.release();
+    } catch (const std::exception &e) {
+        set_error("lines_shard: %s", e.what());
+        return MORNA_E_INVALID;
+    }
+    return MORNA_OK;
+}
+
+// info[4] = {rank, world, id_offset (global id of local id 0), n_items of the whole data set}
+int morna_lines_shard_info(const morna_lines *L, int64_t *info)
+{
+    if (!L || !info) return MORNA_E_INVALID;
+    info[0] = L->shard_rank;
+    info[1] = L->shard_world;
+    info[2] = L->id_offset;
+    info[3] = L->n_items_global >= 0 ? L->n_items_global : (int64_t)L->ext_ids.size();
+    return MORNA_OK;
+}
+
+// Lines handed over as arrays (a Python-side parse, a synthetic data set): the same object the parser makes, so that the
+// shard cut and the staging have ONE implementation.  ext_ids[n_items]: external sample id of every internal id.
+int morna_lines_from_arrays(const uint8_t *key_bytes, const int64_t *key_off, int64_t J, const int64_t *row_ptr,
+                            const int32_t *item_ids, const int32_t *cov, const double *idf, const int64_t *ext_ids,
+                            int64_t n_items, int64_t sample_count, morna_lines **out)
+{
+    if (!out || J < 0 || n_items < 0 || (J > 0 && (!key_bytes || !key_off || !row_ptr || !item_ids || !cov || !idf)) ||
+        (n_items > 0 && !ext_ids)) {
+        set_error("lines_from_arrays: null argument");
+        return MORNA_E_INVALID;
+    }
+    *out = nullptr;
+    if (J > 0 && (key_off[0] != 0 || row_ptr[0] != 0)) {
+        set_error("lines_from_arrays: offsets must start at 0");
+        return MORNA_E_INVALID;
+    }
+    for (int64_t j = 0; j < J; j++)
+        if (key_off[j + 1] < key_off[j] || row_ptr[j + 1] < row_ptr[j]) {
+            set_error("lines_from_arrays: offsets must be non-decreasing (line %lld)", (long long)j);
+            return MORNA_E_INVALID;
+        }
+    const int64_t nnz = J ? row_ptr[J] : 0;
+    for (int64_t t = 0; t < nnz; t++)
+        if (item_ids[t] < 0 || item_ids[t] >= n_items) {
+            set_error("lines_from_arrays: item id %d out of range [0, %lld)", item_ids[t], (long long)n_items);
+            return MORNA_E_RANGE;
+        }
+    try {
+        std::unique_ptr<morna_lines> L(new morna_lines());
+        if (J > 0) {
+            L->key_bytes.assign(key_bytes, key_bytes + key_off[J]);
+            L->key_off.assign(key_off, key_off + J + 1);
+            L->row_ptr.assign(row_ptr, row_ptr + J + 1);
+            L->item_ids.assign(item_ids, item_ids + nnz);
+            L->cov.assign(cov, cov + nnz);
+            L->idf.assign(idf, idf + J);
+        }
+        if (n_items > 0) L->ext_ids.assign(ext_ids, ext_ids + n_items);
+        L->sample_count = sample_count;
+        *out = L.release();
+    } catch (const std::exception &e) {
+        set_error("lines_from_arrays: %s", e.what());
+        return MORNA_E_INVALID;
     }
     return MORNA_OK;
 }

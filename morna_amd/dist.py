@@ -16,66 +16,7 @@ import torch
 import torch.distributed as dist
 
 
-def merge_topk(ids, dists, k):
-    """ids/dists: [world, nq, k] (id -1 / dist inf = empty slot).  Returns the k
-    smallest (distance, id) pairs per query as ([nq, k] ids, [nq, k] dists, [nq] counts)."""
-    world, nq, kk = ids.shape
-    flat_ids = np.transpose(ids, (1, 0, 2)).reshape(nq, world * kk)
-    flat_d = np.transpose(dists, (1, 0, 2)).reshape(nq, world * kk)
-    flat_d = np.where(flat_ids < 0, np.inf, flat_d)
-    key_ids = np.where(flat_ids < 0, np.iinfo(np.int64).max, flat_ids)
-    if nq == 0:
-        return np.full((0, k), -1, np.int64), np.full((0, k), np.inf, flat_d.dtype), np.zeros(0, np.int32)
-    # primary distance, then id: annoy's pair sort; empty slots (inf, max id) sort last
-    order = np.lexsort((key_ids, flat_d), axis=1)[:, :k]
-    out_ids = np.take_along_axis(flat_ids, order, axis=1)
-    out_d = np.take_along_axis(flat_d, order, axis=1)
-    if out_ids.shape[1] < k:                                   # fewer slots than k in total
-        pad = k - out_ids.shape[1]
-        out_ids = np.concatenate([out_ids, np.full((nq, pad), -1, np.int64)], axis=1)
-        out_d = np.concatenate([out_d, np.full((nq, pad), np.inf, out_d.dtype)], axis=1)
-    counts = (out_ids >= 0).sum(axis=1).astype(np.int32)
-    out_d = np.where(out_ids >= 0, out_d, np.inf)
-    return out_ids.astype(np.int64), out_d, counts
-
-
-def merge_topk_native(ids, dists, k):
-    """merge_topk through the library (morna_merge_topk: a k-way merge of the sorted per-shard lists, C++
-    on the host): the numpy lexsort above takes as long as a whole build + query step at 8 shards."""
-    import ctypes as C
-    from ._lib import check, lib
-    world, nq, kk = ids.shape
-    ids = np.ascontiguousarray(ids, np.int64)
-    dists = np.ascontiguousarray(dists, np.float32)
-    out_ids = np.empty((nq, k), np.int64)
-    out_d = np.empty((nq, k), np.float32)
-    cnt = np.empty(nq, np.int32)
-    if nq:
-        check(lib().morna_merge_topk(ids.ctypes.data_as(C.c_void_p), dists.ctypes.data_as(C.c_void_p), world, nq, kk, k,
-                                     out_ids.ctypes.data_as(C.c_void_p), out_d.ctypes.data_as(C.c_void_p),
-                                     cnt.ctypes.data_as(C.c_void_p)))
-    return out_ids, out_d, cnt
-
-
-def merge_topk_exact(ids, dists, k):
-    """Merge of per-shard exact_search_nn results ([world, nq, k], fp64 distances): what the
-    reference's bisect_left scan over ALL rows would keep -- ascending distance, and among equal
-    distances the HIGHER global id first (morna.py:705-712).  NaN distances sort last."""
-    world, nq, kk = ids.shape
-    flat_ids = np.transpose(ids, (1, 0, 2)).reshape(nq, world * kk).astype(np.int64)
-    flat_d = np.transpose(dists, (1, 0, 2)).reshape(nq, world * kk).astype(np.float64)
-    empty = flat_ids < 0
-    key_d = np.where(empty | np.isnan(flat_d), np.inf, flat_d)
-    rank_last = (empty * 2 + (np.isnan(flat_d) & ~empty) * 1).astype(np.int64)       # real < NaN < empty
-    order = np.lexsort((-flat_ids, key_d, rank_last), axis=1)[:, :k] if nq else np.zeros((0, k), np.int64)
-    out_ids = np.take_along_axis(flat_ids, order, axis=1) if nq else np.zeros((0, k), np.int64)
-    out_d = np.take_along_axis(flat_d, order, axis=1) if nq else np.zeros((0, k))
-    if out_ids.shape[1] < k:
-        pad = k - out_ids.shape[1]
-        out_ids = np.concatenate([out_ids, np.full((nq, pad), -1, np.int64)], axis=1)
-        out_d = np.concatenate([out_d, np.full((nq, pad), np.inf)], axis=1)
-    counts = (out_ids >= 0).sum(axis=1).astype(np.int32)
-    return out_ids, np.where(out_ids >= 0, out_d, np.inf), counts
+from .shards import merge_topk, merge_topk_exact, merge_topk_native   # noqa: E402,F401  (re-exported: tests and callers import them from here)
 
 
 class ShardedSearch(object):

@@ -142,6 +142,10 @@ class MornaIndex(AnnoyIndex):
     def save(self, basename):
         """Index file set of the reference (morna.py:427-455), minus the sqlite shards."""
         super(MornaIndex, self).save(basename + '.annoy.mor')
+        self._save_global(basename)
+
+    def _save_global(self, basename):
+        """Everything of the file set but the matrix + forest blob."""
         with open(basename + ".stats.mor", 'w') as stats_stream:
             stats_stream.write(str(self.sample_count) + "\n")
             stats_stream.write(str(self.new_internal_id) + "\n")
@@ -162,11 +166,16 @@ def tokenize_line(line):
             [int(c) for c in tokens[-1].split(',')])
 
 
+class _OwnedArrays(dict):
+    """views into memory of a ParsedLines: holds the owner so that they stay valid as long as the dict does"""
+    owner = None
+
+
 class ParsedLines(object):
     """Result of the native pre-pass (morna_parse_intropolis): the kept junction
     lines of an intropolis file as the arrays the C ABI stages, owned by the library."""
 
-    def __init__(self, path, sample_count=None, sample_threshold=100, cache=None):
+    def __init__(self, path, sample_count=None, sample_threshold=100, cache=None, _ptr=None):
         """cache: path of the binary pre-tokenised cache.  It is used when it was written from this very
         file (same size and mtime) with the same sample_count argument and threshold; otherwise the
         file is parsed and the cache (re)written."""
@@ -175,6 +184,10 @@ class ParsedLines(object):
         from ._lib import check, lib
         self._p = C.c_void_p()
         self.from_cache = False
+        if _ptr is not None:                     # lines the library already holds (from_arrays, shard)
+            self._p = _ptr
+            self._read_counts()
+            return
         tag = None
         if cache:
             st = os.stat(path)
@@ -192,20 +205,55 @@ class ParsedLines(object):
                                                C.byref(self._p)))
             if cache:
                 check(lib().morna_lines_save(self._p, str(cache).encode(), tag.ctypes.data_as(C.c_void_p)))
+        self._read_counts()
+
+    def _read_counts(self):
+        import ctypes as C
+        from ._lib import check, lib
         counts = np.zeros(8, np.int64)
         check(lib().morna_lines_counts(self._p, counts.ctypes.data_as(C.c_void_p)))
         (self.n_lines, self.nnz, self.n_items, self.skipped, self.sample_count, self.key_bytes_n,
          self.n_keys, self.lines_read) = [int(x) for x in counts]
+        info = np.zeros(4, np.int64)
+        check(lib().morna_lines_shard_info(self._p, info.ctypes.data_as(C.c_void_p)))
+        self.shard_rank, self.shard_world, self.id_offset, self.n_items_global = [int(x) for x in info]
+
+    @classmethod
+    def from_arrays(cls, prep, sample_count):
+        """Lines tokenised by the caller (prepare_csr's dict, MornaIndex's buffer): key_bytes, key_off, row_ptr, ids,
+        cov, idf, ext_ids."""
+        import ctypes as C
+        from ._lib import check, lib, ptr
+        a = {k: np.ascontiguousarray(prep[k], dtype=t) for k, t in (
+            ("key_bytes", np.uint8), ("key_off", np.int64), ("row_ptr", np.int64), ("ids", np.int32), ("cov", np.int32),
+            ("idf", np.float64), ("ext_ids", np.int64))}
+        p = C.c_void_p()
+        check(lib().morna_lines_from_arrays(ptr(a["key_bytes"]), ptr(a["key_off"]), len(a["idf"]), ptr(a["row_ptr"]),
+                                            ptr(a["ids"]), ptr(a["cov"]), ptr(a["idf"]), ptr(a["ext_ids"]),
+                                            len(a["ext_ids"]), int(sample_count), C.byref(p)))
+        return cls(None, _ptr=p)
+
+    def shard(self, rank, world):
+        """The lines of row shard `rank` of `world` (morna_lines_shard): global idf and first-seen ids, entries of the
+        shard's own items only, ids renumbered from 0."""
+        import ctypes as C
+        from ._lib import check, lib
+        p = C.c_void_p()
+        check(lib().morna_lines_shard(self._p, int(rank), int(world), C.byref(p)))
+        return ParsedLines(None, _ptr=p)
 
     def __del__(self):
         p = getattr(self, "_p", None)
         if p is not None and p.value:
-            from ._lib import lib
-            lib().morna_lines_free(p)
+            try:
+                from ._lib import lib
+                lib().morna_lines_free(p)
+            except Exception:                          # interpreter shutting down
+                pass
             self._p = None
 
     def arrays(self):
-        """numpy views of the library-owned arrays (valid while this object lives)."""
+        """numpy views of the library-owned arrays.  The dict keeps this object (and with it the arrays) alive."""
         import ctypes as C
         from ._lib import check, lib
         ptrs = [C.c_void_p() for _ in range(7)]
@@ -215,11 +263,13 @@ class ParsedLines(object):
             if n == 0 or not p.value:
                 return np.zeros(0, dtype=np.dtype(ctype))
             return np.ctypeslib.as_array(C.cast(p, C.POINTER(ctype)), shape=(n,))
-        return dict(key_bytes=view(ptrs[0], C.c_uint8, self.key_bytes_n),
-                    key_off=view(ptrs[1], C.c_int64, self.n_lines + 1),
-                    row_ptr=view(ptrs[2], C.c_int64, self.n_lines + 1),
-                    ids=view(ptrs[3], C.c_int32, self.nnz), cov=view(ptrs[4], C.c_int32, self.nnz),
-                    idf=view(ptrs[5], C.c_double, self.n_lines), ext_ids=view(ptrs[6], C.c_int64, self.n_items))
+        out = _OwnedArrays(key_bytes=view(ptrs[0], C.c_uint8, self.key_bytes_n),
+                           key_off=view(ptrs[1], C.c_int64, self.n_lines + 1),
+                           row_ptr=view(ptrs[2], C.c_int64, self.n_lines + 1),
+                           ids=view(ptrs[3], C.c_int32, self.nnz), cov=view(ptrs[4], C.c_int32, self.nnz),
+                           idf=view(ptrs[5], C.c_double, self.n_lines), ext_ids=view(ptrs[6], C.c_int64, self.n_items))
+        out.owner = self
+        return out
 
     def frequencies(self):
         """junction -> cumulative sample frequency (MornaIndex.sample_frequencies)."""
@@ -237,14 +287,68 @@ class ParsedLines(object):
         check(lib().morna_stage_lines(index._h, self._p))
 
 
+def shard_bounds(n_items, world):
+    """Global id range of every row shard: rank g owns [g * ceil(N / G), (g + 1) * ceil(N / G))."""
+    per = (int(n_items) + world - 1) // world
+    return [min(int(n_items), per * g) for g in range(world + 1)]
+
+
+def shard_basename(basename, rank, world):
+    """File-set prefix of one row shard's matrix + forest blob."""
+    return "%s.shard%dof%d" % (basename, rank, world)
+
+
+def shard_csr(prep, rank, world):
+    """prepare_csr's result cut to row shard `rank` of `world`: what morna_lines_shard does, in numpy (the lines keep the
+    GLOBAL idf; a line's entries are those of the shard's items, ids from 0; empty lines go)."""
+    lo, hi = shard_bounds(prep["n_items"], world)[rank:rank + 2]
+    ids = np.asarray(prep["ids"])
+    keep = (ids >= lo) & (ids < hi)
+    lens = np.add.reduceat(keep.astype(np.int64), prep["row_ptr"][:-1]) if len(prep["idf"]) else np.zeros(0, np.int64)
+    lens[np.diff(prep["row_ptr"]) == 0] = 0                     # reduceat returns the next element for an empty slice
+    lines = np.nonzero(lens)[0]
+    row_ptr = np.zeros(len(lines) + 1, np.int64)
+    row_ptr[1:] = np.cumsum(lens[lines])
+    klen = np.diff(prep["key_off"])
+    key_off = np.zeros(len(lines) + 1, np.int64)
+    key_off[1:] = np.cumsum(klen[lines])
+    kb = np.asarray(prep["key_bytes"])
+    key_bytes = kb[np.repeat(np.isin(np.arange(len(klen)), lines), klen)] if len(lines) else np.zeros(0, np.uint8)
+    return dict(key_bytes=key_bytes, key_off=key_off, row_ptr=row_ptr, ids=(ids[keep] - lo).astype(np.int32),
+                cov=np.asarray(prep["cov"])[keep], idf=np.asarray(prep["idf"])[lines], n_items=hi - lo,
+                ext_ids=np.asarray(prep["ext_ids"])[lo:hi], id_offset=lo, n_items_global=prep["n_items"])
+
+
+def build_shard(parsed, features, n_trees, rank, world, device=0, seed=0):
+    """Row shard `rank` of `world` of ONE parsed data set: its lines (global idf, global first-seen ids), its feature
+    matrix and its own forest.  Returns (AnnoyIndex, id_offset, n_local)."""
+    part = parsed.shard(rank, world) if world > 1 else parsed
+    a = AnnoyIndex(features, metric='angular', device=device)
+    if part.n_items == 0:
+        raise ValueError("row shard %d of %d is empty: %d samples do not fill %d shards" % (rank, world, parsed.n_items, world))
+    part.stage(a)
+    a.build_features(part.n_items)
+    a.unstage_junctions()
+    a.build(n_trees, seed=seed)
+    return a, part.id_offset, part.n_items
+
+
 def go_index_native(intropolis, basename, features, n_trees, sample_count, sample_threshold, buffer_size, verbose,
-                    metafile, device=0, save=True, seed=0, cache=None):
+                    metafile, device=0, save=True, seed=0, cache=None, shards=1, rank=None):
     """go_index with the tokenising loop done by the library (morna_parse_intropolis)
     instead of the Python interpreter; same index, same files.  `cache`: binary
-    pre-tokenised cache file to reuse / write (ParsedLines)."""
+    pre-tokenised cache file to reuse / write (ParsedLines).
+
+    shards > 1: the rows are cut into `shards` contiguous ranges of internal ids, each with its own matrix + forest
+    blob (<basename>.shard<g>of<G>.annoy.mor); the global files (.stats / .freq / .map / .shards.mor) describe the
+    whole index.  rank=None builds every shard in this process, one after the other; rank=g builds shard g only (one
+    process per GPU) and rank 0 writes the global files."""
     parsed = ParsedLines(intropolis, sample_count, sample_threshold, cache=cache)
     if verbose:
         print('\nThere are {} samples.'.format(parsed.sample_count))
+    if shards > 1:
+        return _go_index_sharded(parsed, basename, features, n_trees, sample_threshold, buffer_size, verbose, metafile,
+                                 device, save, seed, shards, rank)
     morna_index = MornaIndex(parsed.sample_count, basename, dim=features, sample_threshold=sample_threshold,
                              metafile=metafile, buffer_size=buffer_size, device=device)
     morna_index.junc_id = parsed.lines_read - 1
@@ -265,12 +369,38 @@ def go_index_native(intropolis, basename, features, n_trees, sample_count, sampl
     return morna_index
 
 
+def _go_index_sharded(parsed, basename, features, n_trees, sample_threshold, buffer_size, verbose, metafile, device,
+                      save, seed, shards, rank):
+    if parsed.n_items == 0:
+        raise ValueError("No internal ids were assigned, indicating that no samples were added to the index. "
+                         "Likely caused when no junctions pass the sample threshold.")
+    bounds = shard_bounds(parsed.n_items, shards)
+    built = []
+    for g in (range(shards) if rank is None else [rank]):
+        a, off, n = build_shard(parsed, features, n_trees, g, shards, device=device, seed=seed)
+        assert (off, off + n) == (bounds[g], bounds[g + 1])
+        if save:
+            a.save(shard_basename(basename, g, shards) + '.annoy.mor')
+        built.append(a)
+    if save and (rank is None or rank == 0):
+        # the files that describe the WHOLE index: as MornaIndex.save writes them (morna.py:443-455), ids global
+        head = MornaIndex.__new__(MornaIndex)
+        head.sample_count, head.new_internal_id, head.dim, head.metafile = parsed.sample_count, parsed.n_items, features, metafile
+        head.sample_frequencies = parsed.frequencies()
+        head.internal_id_map = {int(s): i for i, s in enumerate(parsed.arrays()["ext_ids"].tolist())}
+        head._save_global(basename)
+        with open(basename + ".shards.mor", "w") as fh:
+            fh.write(str(shards) + "\n" + " ".join(str(b) for b in bounds) + "\n")
+    return built if rank is None else built[0]
+
+
 def go_index(intropolis, basename, features, n_trees, sample_count, sample_threshold, buffer_size, verbose,
-             metafile, device=0, save=True, seed=0, native=False, cache=None):
+             metafile, device=0, save=True, seed=0, native=False, cache=None, shards=1, rank=None):
     """`morna index` (morna.py:824-865): gzipped intropolis file -> index files."""
-    if native or cache:
+    if native or cache or shards > 1:
         return go_index_native(intropolis, basename, features, n_trees, sample_count, sample_threshold, buffer_size,
-                               verbose, metafile, device=device, save=save, seed=seed, cache=cache)
+                               verbose, metafile, device=device, save=save, seed=seed, cache=cache, shards=shards,
+                               rank=rank)
     if not sample_count:
         with gzip.open(intropolis, "rt") as introp_file_handle:
             sample_count = count_samples(introp_file_handle, verbose)
@@ -326,13 +456,25 @@ def prepare_csr(keys, row_ptr, samples, cov, sample_count, sample_threshold):
         mask = np.repeat(keep, lens)
         s_kept = samples[row_ptr[0]:row_ptr[-1]][mask]
         c_kept = cov[row_ptr[0]:row_ptr[-1]][mask].astype(np.int32)
-    # first-seen order of sample ids
-    uniq, first = np.unique(s_kept, return_index=True)
-    order = np.argsort(first, kind="stable")
-    ext_ids = uniq[order]
-    rank = np.empty(len(uniq), np.int64)
-    rank[order] = np.arange(len(uniq))
-    ids = rank[np.searchsorted(uniq, s_kept)].astype(np.int32)
+    # first-seen order of sample ids (morna.py:377-382)
+    if len(s_kept) and s_kept.dtype.kind in "iu" and int(s_kept.min()) >= 0 and int(s_kept.max()) < (1 << 27):
+        # small non-negative ids: a table indexed by the id.  Assigning the positions in REVERSE leaves each id's first
+        # position in its slot (numpy stores repeated indices in order, the last store wins)
+        first_at = np.full(int(s_kept.max()) + 1, -1, np.int64)
+        first_at[s_kept[::-1]] = np.arange(len(s_kept) - 1, -1, -1, dtype=np.int64)
+        uniq = np.nonzero(first_at >= 0)[0].astype(s_kept.dtype)
+        order = np.argsort(first_at[uniq], kind="stable")
+        ext_ids = uniq[order]
+        table = np.zeros(len(first_at), np.int32)
+        table[ext_ids] = np.arange(len(ext_ids), dtype=np.int32)
+        ids = table[s_kept]
+    else:
+        uniq, first = np.unique(s_kept, return_index=True)
+        order = np.argsort(first, kind="stable")
+        ext_ids = uniq[order]
+        rank = np.empty(len(uniq), np.int64)
+        rank[order] = np.arange(len(uniq))
+        ids = rank[np.searchsorted(uniq, s_kept)].astype(np.int32)
     new_row_ptr = np.zeros(len(kept) + 1, np.int64)
     new_row_ptr[1:] = np.cumsum(lens[kept])
     key_off = np.zeros(len(kept) + 1, np.int64)

@@ -10,6 +10,7 @@ the searches run in libmorna_hip.so.
 `meta_db=True` appends the keywords of `<basename>.meta.mor` to the results
 (morna.py:666-676; metadb.py).
 """
+import os
 import pickle
 import sys
 from collections import defaultdict
@@ -41,8 +42,12 @@ class MornaSearch(object):
             self.dim = int(stats_stream.readline())
         self.query = defaultdict(int)
         self.query_sample = [0.0 for _ in range(self.dim)]
-        self.annoy_index = AnnoyIndex(self.dim, metric="angular", device=device)
-        self.annoy_index.load(basename + '.annoy.mor')
+        if os.path.exists(basename + ".shards.mor"):           # written by `morna index --shards G` (index.py)
+            from .shards import LocalShards
+            self.annoy_index = LocalShards(basename, self.dim, device=device)
+        else:
+            self.annoy_index = AnnoyIndex(self.dim, metric="angular", device=device)
+            self.annoy_index.load(basename + '.annoy.mor')
         with open(basename + ".freq.mor", "rb") as pickle_stream:
             self.sample_frequencies = defaultdict(int, pickle.load(pickle_stream))
         with open(basename + ".map.mor", "rb") as pickle_stream:

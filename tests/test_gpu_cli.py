@@ -234,3 +234,62 @@ def test_cli_index_from_pretokenised_cache(tmp_path, embedded):
         blobs = [open(str(tmp_path / b) + ext, "rb").read() for b in ("plain", "c1", "c2")]
         assert blobs[0] == blobs[1] == blobs[2], ext
     assert MornaSearch(str(tmp_path / "c2")).search_member_n(3, 4, 100)[0][0] == 2
+
+
+def test_cli_index_shards_then_search_equals_unsharded(tmp_path):
+    """`morna index --shards 3`: one file cut into three row shards with the GLOBAL idf and first-seen
+    ids, each with its own matrix + forest file; `morna search` on that file set answers as on the unsharded index --
+    the exact search identically (ids and fp64 distances, stream query and --exact), by-member and approximate
+    queries with the same nearest neighbour and global ids."""
+    import pickle
+    from morna_amd import cli
+    from morna_amd.index import shard_bounds, shard_basename
+    from morna_amd.search import MornaSearch
+    from morna_amd.synth import synthetic_intropolis
+    d = synthetic_intropolis(700, J=900)
+    src = str(tmp_path / "i.tsv.gz")
+    lines = []
+    for j, k in enumerate(d["keys"]):
+        lo, hi = d["row_ptr"][j], d["row_ptr"][j + 1]
+        lines.append("\t".join(k.split(" ") + ["+", "GT", "AG", ",".join(map(str, d["samples"][lo:hi])),
+                                               ",".join(map(str, d["cov"][lo:hi]))]) + "\n")
+    _write_gz(src, lines)
+    one, three = str(tmp_path / "one"), str(tmp_path / "three")
+    assert cli.main(["index", "--intropolis", src, "-x", one, "--features", "96", "--n-trees", "6", "-t", "40"]) == 0
+    assert cli.main(["index", "--intropolis", src, "-x", three, "--features", "96", "--n-trees", "6", "-t", "40",
+                     "--shards", "3"]) == 0
+    for ext in (".stats.mor", ".freq.mor", ".map.mor"):
+        with open(one + ext, "rb") as f1, open(three + ext, "rb") as f2:
+            assert (f1.read() == f2.read()) if ext == ".stats.mor" else (pickle.load(f1) == pickle.load(f2))
+    s1, s3 = MornaSearch(basename=one), MornaSearch(basename=three)
+    N = s1.index_size
+    assert s3.annoy_index.get_n_items() == N and s3.annoy_index.offsets.tolist() == shard_bounds(N, 3)
+    X = s1.annoy_index.get_items()
+    stacked = np.concatenate([sh.get_items() for sh in s3.annoy_index.shards])
+    assert stacked.tobytes() == X.tobytes()
+    for g in range(3):
+        assert os.path.exists(shard_basename(three, g, 3) + ".annoy.mor")
+    # a stream query made of one sample's junctions
+    sample = int(d["samples"][d["row_ptr"][5]])
+    q = []
+    for j, k in enumerate(d["keys"]):
+        lo, hi = d["row_ptr"][j], d["row_ptr"][j + 1]
+        hit = np.nonzero(d["samples"][lo:hi] == sample)[0]
+        if len(hit):
+            c, a, b = k.split(" ")
+            q.append("%s\t%s\t%s\t%d\n" % (c, a, b, d["cov"][lo + hit[0]]))
+    outs = []
+    for base in (one, three):
+        out = io.StringIO()
+        assert cli.main(["search", "-x", base, "-f", "raw", "--exact", "-d", "-r", "8"], stdin=io.StringIO("".join(q)), stdout=out) == 0
+        outs.append(out.getvalue())
+    assert outs[0] == outs[1] and len(outs[0].strip().split("\n")) == 8
+    a1 = s1.search_member_n(sample, 10, -1, include_distances=True)
+    a3 = s3.search_member_n(sample, 10, -1, include_distances=True)
+    assert a1[0][0] == a3[0][0] == s1.internal_id_map[sample] and a3[1][0] < 1e-3
+    # search_k = -1 with 6 trees per forest inspects 60 candidates per forest: the sharded answer's distances are the true
+    # distances of its (global) ids
+    assert np.allclose(a3[1], np.sqrt(np.maximum(angular64(X, a3[0][0])[a3[0]], 0)), atol=2e-6)
+    assert s3.annoy_index.get_item_vector(N - 1) == s1.annoy_index.get_item_vector(N - 1)
+    with pytest.raises(IndexError):
+        s3.annoy_index.get_item_vector(N)

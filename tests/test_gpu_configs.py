@@ -6,8 +6,11 @@
               number only, so tree t of a 200-tree forest IS tree t of an 8-tree forest); invariants over all 200;
               every returned distance = the fp64 angular distance of the returned id; recall@20 against the exact
               search, and against the FAITHFUL annoy restatement (oracle mode 0) at 24 trees, same search_k.
-  configs[3]  the 25k x 3000 shard a GPU holds of the 200k-sample index, through ShardedSearch on a 1-rank RCCL
-              group (the 8-GPU run itself is the driver's).
+  configs[3]  rows cut into shards of ONE data set (global idf, global first-seen ids): the 50k set cut 8 ways in one
+              process and 2 ways over two ranks (gloo, one device) -- stacked shard matrices byte-identical to the single
+              index, sharded exact search identical, approximate recall not worse; a 25k x 3000 shard through
+              ShardedSearch on a 1-rank RCCL group (the 8-GPU run itself is the driver's; the 200k-sample set is cut by
+              scripts/c4_200k_shard.py, profiles/r03_c4_200k_shard.json).
   configs[4]  50k x 8192 exact all-pairs: one GPU's 6250-row shard, all 6250 rows as queries (morna.py:681-716
               for every item), ids and fp64 distances against the oracle on a 64-query sample.
 
@@ -175,27 +178,128 @@ def test_c3_eight_trees_bit_exact_vs_oracle_mode1(c3, capi):
             assert d[qi, :m].tobytes() == np.array(rd, np.float32).tobytes(), (it, sk)
 
 
-def test_c4_shard_25k_through_sharded_search_one_rank_rccl(capi):
-    """configs[3]: what ONE of the 8 GPUs does for the 200k-sample index -- a 25k x 3000 shard with its own
-    200-tree forest, queried through ShardedSearch (query rows stay in HBM, top-k all-gather over RCCL, merge)."""
+def _build_shard_from_prep(prep, sample_count, rank, world, n_trees, device=0):
+    """Row shard `rank` of `world` of the data set behind `prep`: lines cut by the library (global idf, global first-seen
+    ids), feature matrix, forest.  Returns (index, id_offset, n_local)."""
+    from morna_amd.index import ParsedLines, build_shard
+    return build_shard(ParsedLines.from_arrays(prep, sample_count), D3, n_trees, rank, world, device=device)
+
+
+def test_c4_eight_way_cut_of_one_data_set_stacks_to_the_single_index(c3):
+    """configs[3]'s partition (rows cut 8 ways) applied to the 50k data set: eight 6250-row shards, each
+    built from ITS lines with the GLOBAL idf and global first-seen ids -- stacked, they are the single index's matrix
+    byte for byte (which test_c3_feature_matrix_bit_exact_vs_oracle pins to the oracle), and the row-sharded exact
+    search is the single index's exact search."""
+    from morna_amd.index import shard_bounds
+    from morna_amd.shards import merge_topk_exact, merge_topk_native
+    X, N, prep = c3["X"], c3["N"], c3["prep"]
+    world = 8
+    bounds = shard_bounds(N, world)
+    assert bounds == [6250 * g for g in range(9)]
+    items = c3["items"][:96]
+    Q = X[items]
+    ex, ap = [], []
+    for g in range(world):
+        a, off, n = _build_shard_from_prep(prep, c3["data"]["sample_count"], g, world, 20)
+        assert (off, n) == (bounds[g], 6250)
+        assert a.get_items().tobytes() == X[off:off + n].tobytes(), g
+        assert a.get_norms2().tobytes() == c3["index"].get_norms2()[off:off + n].tobytes(), g
+        ex.append(a.exact_search_batch(Q.astype(np.float64), K3))
+        ap.append(a.get_nns_by_vector_batch(Q, K3, SEARCH_K))
+        del a
+    glob = lambda g, ids: np.where(ids >= 0, ids.astype(np.int64) + bounds[g], -1)     # noqa: E731
+    eids, ed, ecnt = merge_topk_exact(np.stack([glob(g, r[0]) for g, r in enumerate(ex)]), np.stack([r[1] for r in ex]), K3)
+    wids, wd, wcnt = c3["index"].exact_search_batch(Q.astype(np.float64), K3)
+    assert eids.tolist() == wids.astype(np.int64).tolist() and ed.tobytes() == wd.tobytes() and ecnt.tolist() == wcnt.tolist()
+    # approximate: eight 20-tree forests inspect at least what one 200-tree forest does (one leaf per shard at search_k = 100)
+    aids = merge_topk_native(np.stack([glob(g, r[0]) for g, r in enumerate(ap)]), np.stack([r[1] for r in ap]), K3)[0]
+    wa = c3["index"].get_nns_by_item_batch(items, K3, SEARCH_K)[0]
+    rec_s = np.mean([len(set(aids[i].tolist()) & set(wids[i].tolist())) / float(K3) for i in range(len(items))])
+    rec_w = np.mean([len(set(wa[i].tolist()) & set(wids[i].tolist())) / float(K3) for i in range(len(items))])
+    assert rec_s >= rec_w - 0.02, (rec_s, rec_w)
+
+
+def _two_way_worker(rank, world, port, tmp, ret):
     import torch
     import torch.distributed as dist
-    from morna_amd.annoy import AnnoyIndex
     from morna_amd.dist import ShardedSearch
-    from morna_amd.index import prepare_csr
-    from morna_amd.synth import query_items, synthetic_intropolis
-    data = synthetic_intropolis(25_000, J=70_000)
-    prep = prepare_csr(data["keys"], data["row_ptr"], data["samples"], data["cov"], data["sample_count"], 100)
-    N = prep["n_items"]
-    a = AnnoyIndex(D3)
-    a.stage_junctions(prep["key_bytes"], prep["key_off"], prep["row_ptr"], prep["ids"], prep["cov"], prep["idf"])
-    a.build_features(N)
-    a.build(T3, seed=0)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        z = np.load(os.path.join(tmp, "prep.npz"))
+        prep = {k: z[k] for k in z.files}
+        prep["n_items"] = int(prep.pop("n_items"))
+        X = np.load(os.path.join(tmp, "X.npy"), mmap_mode="r")
+        want = np.load(os.path.join(tmp, "want.npz"))
+        a, off, n = _build_shard_from_prep(prep, int(prep.pop("sample_count")), rank, world, T3)
+        assert (off, n) == (25_000 * rank, 25_000)
+        assert a.get_items().tobytes() == np.ascontiguousarray(X[off:off + n]).tobytes()   # this rank's rows of the ONE matrix
+        _check_forest(a, n, T3, D3 + 2)
+        ss = ShardedSearch(a, rank, world, n)
+        assert ss.offsets.tolist() == [0, 25_000, 50_000]
+        items = want["items"]
+        Q = np.ascontiguousarray(X[items])
+        eids, ed, ecnt = ss.exact_search(Q.astype(np.float64), K3)
+        assert eids.tolist() == want["eids"].astype(np.int64).tolist() and ed.tobytes() == want["ed"].tobytes()
+        assert ecnt.tolist() == want["ecnt"].tolist()
+        ids, d, cnt = ss.get_nns_by_vector(Q, K3, SEARCH_K)
+        assert (cnt == K3).all()
+        rec_s = np.mean([len(set(ids[i].tolist()) & set(eids[i].tolist())) / float(K3) for i in range(len(items))])
+        assert rec_s >= float(want["recall_single"]) - 0.01, (rec_s, float(want["recall_single"]))
+        # by item: every rank asks about rows of ITS shard (the form bench.py's strong-scaling run uses)
+        mine = items[(items >= off) & (items < off + n)] - off
+        n_each = [int(((items >= 25_000 * g) & (items < 25_000 * (g + 1))).sum()) for g in range(world)]
+        ids2, d2, cnt2 = ss.get_nns_by_local_items(mine.astype(np.int32), K3, SEARCH_K, n_each=n_each)
+        order = np.concatenate([np.nonzero((items >= 25_000 * g) & (items < 25_000 * (g + 1)))[0] for g in range(world)])
+        assert ids2.tolist() == ids[order].tolist() and np.asarray(d2).tobytes() == np.asarray(d)[order].tobytes()
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c3_two_way_cut_two_ranks_real_shards_gloo(c3, tmp_path):
+    """ONE synthetic_intropolis(50_000) cut into two row shards, one per rank (two processes sharing the
+    device, gloo between them -- RCCL refuses two ranks on one GPU): each rank's matrix is its rows of the single index's
+    matrix byte for byte; the sharded exact search equals the single index's (ids + fp64 distances); the sharded
+    approximate search is not worse in recall than the single 200-tree index."""
+    import torch.multiprocessing as mp
+    prep = c3["prep"]
+    np.savez(tmp_path / "prep.npz", sample_count=c3["data"]["sample_count"],
+             **{k: (np.asarray(v) if k != "freq" else np.zeros(0)) for k, v in prep.items() if k not in ("freq", "X_host")})
+    np.save(tmp_path / "X.npy", c3["X"])
+    items = np.sort(c3["items"][:128])
+    a = c3["index"]
+    eids, ed, ecnt = a.exact_search_batch(c3["X"][items].astype(np.float64), K3)
+    sids = a.get_nns_by_item_batch(items, K3, SEARCH_K)[0]
+    rec = np.mean([len(set(sids[i].tolist()) & set(eids[i].tolist())) / float(K3) for i in range(len(items))])
+    np.savez(tmp_path / "want.npz", items=items, eids=eids, ed=ed, ecnt=ecnt, recall_single=rec)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_two_way_worker, args=(2, port, str(tmp_path), ret), nprocs=2, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def test_c4_shard_25k_through_sharded_search_one_rank_rccl(c3, capi):
+    """configs[3]: what ONE GPU of a row-sharded index does -- a 25k x 3000 shard (the second half of the 50k data set cut
+    two ways: global idf and ids, not a data set of its own) with its own 200-tree forest, queried through ShardedSearch
+    on a 1-rank RCCL group (query rows stay in HBM, top-k all-gather over RCCL, merge kernel).  The 200k-sample set of
+    configs[3] itself is generated and cut 8 ways by scripts/c4_200k_shard.py (profiles/r03_c4_200k_shard.json): its host
+    generation takes minutes, too long for this suite."""
+    import torch
+    import torch.distributed as dist
+    from morna_amd.dist import ShardedSearch
+    from morna_amd.synth import query_items
+    a, off, N = _build_shard_from_prep(c3["prep"], c3["data"]["sample_count"], 1, 2, T3)
+    assert (off, N) == (25_000, 25_000)
     _check_forest(a, N, T3, D3 + 2)
     X = a.get_items()
-    # the shard's matrix against the oracle on a prefix of the lines is covered at 50k; here: rows vs the oracle for
-    # the first 2000 junction lines only would need a second build -- instead the cheap invariant: no empty row
-    assert (np.abs(X).sum(1) > 0).all()
+    assert X.tobytes() == c3["X"][off:].tobytes()
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
