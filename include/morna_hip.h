@@ -146,7 +146,10 @@ int morna_get_norms2(morna_index *h, float *out /* [n] */);
 
 /* ---- forest -------------------------------------------------------------- */
 
-/* AnnoyIndex.build(n_trees); seed 0 selects annoy's default 123456789   morna.py:425 */
+/* AnnoyIndex.build(n_trees); seed 0 selects annoy's default 123456789   morna.py:425
+ * Limit that annoy does not have: the build keeps a hyperplane and a row in registers / LDS and rejects dimensions whose
+ * padded row (dim rounded up to 256 floats) exceeds 8192 floats (MORNA_E_INVALID).  BASELINE's configurations use 3000
+ * and 8192. */
 int morna_build(morna_index *h, int32_t n_trees, uint32_t seed);
 int32_t morna_get_n_trees(const morna_index *h);
 
@@ -184,9 +187,21 @@ int morna_get_nns_by_item(morna_index *h, const int32_t *items, int64_t nq, int3
  * MornaSearch.exact_search_nn + cosine_distance                   morna.py:681-716, 101-114
  * q[nq][dim] fp64 (the un-rounded query_sample); distances fp64, accumulated in
  * the reference's sequential order; ties resolved as bisect_left does.
+ * count_out[q] = -1: the reference RAISES for this query -- some indexed row is so nearly parallel to it that
+ * cosine_distance's radicand rounds below zero and math.sqrt fails (morna.py:101-114); the reference evaluates every row
+ * (morna.py:697-700), so the whole query fails whatever that row's rank would have been.  The lists of such a query are
+ * filled in for diagnosis only; a caller must test the count before it slices by it.
  */
 int morna_exact_search(morna_index *h, const double *q, int64_t nq, int32_t k,
                        int32_t *ids_out, double *dist_out, int32_t *count_out);
+/*
+ * The same with STORED rows as the queries (every item of the index against the index: BASELINE configs[4]): the query
+ * is the item's fp32 row widened to fp64 on the device -- what exact_search_nn sees when query_sample came out of
+ * get_item_vector (morna.py:697-703) -- so nothing but the item numbers crosses PCIe.  The queries are processed in
+ * batches inside the call (scan values of a batch: at most 2 GiB).
+ */
+int morna_exact_search_by_item(morna_index *h, const int32_t *items, int64_t nq, int32_t k,
+                               int32_t *ids_out, double *dist_out, int32_t *count_out);
 
 /*
  * Row-sharded search (one handle per GPU; the reference has no such path): merge of the
@@ -219,6 +234,50 @@ int morna_get_item_vectors_dev(morna_index *h, const int32_t *ids, int64_t n, fl
 int morna_get_stream(morna_index *h, void **stream_out);
 int morna_merge_topk_packed(morna_index *h, const int32_t *gathered_dev, int32_t world, int64_t nq, int32_t kk, int32_t k,
                             int32_t *ids_out, float *dist_out, int32_t *count_out);
+
+/*
+ * ---- row-sharded search with the communicator inside the library ("the RCCL communicator owned by the
+ * handle"; 8e).  One handle per GPU and process; rank g holds the rows with global ids [off[g], off[g+1]) -- off from the
+ * ranks' own item counts, exchanged by the library -- and its own forest.  Every function below is COLLECTIVE: all ranks
+ * call it with the same nq / k / search_k (and the same queries, where queries are passed).  Data path: per-shard search
+ * -> ncclAllGather of the per-shard top-k (Q * k * 8 bytes per rank; exact: Q * (12 k + 4)) on the handle's stream ->
+ * merge kernel; every rank receives the same merged answer (global ids).  RCCL is loaded at run time; without it
+ * morna_comm_init fails and nothing falls back to the host.
+ *   morna_comm_unique_id   ncclGetUniqueId: ONE rank makes the id, the caller hands the 128 bytes to the others (any
+ *                          channel: a file, MPI, torch.distributed's store)
+ *   morna_comm_init        ncclCommInitRank on the handle's device; world <= 64
+ *   morna_comm_info        rank, world and (when offsets != NULL: collective) offsets[world + 1]
+ *   *_by_item_sharded      every rank contributes stored rows of ITS shard as queries (local ids); the answers come back
+ *                          for all ranks' queries, rank 0's first.  n_each[world] = every rank's query count, or NULL
+ *                          (then the counts are exchanged first).  Query rows travel HBM -> xGMI -> HBM.
+ *   exact variants         merged as exact_search_nn's bisect_left scan over ALL rows would (equal distance: higher global
+ *                          id first); count -1 as morna_exact_search, true of the whole matrix if true of one shard
+ */
+#define MORNA_COMM_ID_BYTES 128
+int morna_comm_unique_id(uint8_t *id_out /* [MORNA_COMM_ID_BYTES] */);
+int morna_comm_init(morna_index *h, const uint8_t *id, int32_t rank, int32_t world);
+int morna_comm_destroy(morna_index *h);
+int morna_comm_info(morna_index *h, int32_t *rank, int32_t *world, int64_t *offsets);
+int morna_get_nns_by_vector_sharded(morna_index *h, const float *q, int64_t nq, int32_t k, int32_t search_k,
+                                    int32_t *ids_out, float *dist_out, int32_t *count_out);
+int morna_get_nns_by_item_sharded(morna_index *h, const int32_t *local_items, int64_t n_local, const int64_t *n_each,
+                                  int32_t k, int32_t search_k, int32_t *ids_out, float *dist_out, int32_t *count_out);
+int morna_exact_search_sharded(morna_index *h, const double *q, int64_t nq, int32_t k,
+                               int32_t *ids_out, double *dist_out, int32_t *count_out);
+int morna_exact_search_by_item_sharded(morna_index *h, const int32_t *local_items, int64_t n_local, const int64_t *n_each,
+                                       int32_t k, int32_t *ids_out, double *dist_out, int32_t *count_out);
+/*
+ * The two halves of the exact exchange on their own (a caller with its own transport; tests that lay several shards'
+ * messages side by side): the per-shard answers packed in HBM -- morna_exact_packed_bytes(nq, k) bytes: ids int32
+ * [nq][k] (local + id_offset, -1 = empty) | count int32 [nq] | pad to 8 | distances fp64 [nq][k]; queries: exactly one
+ * of q (host fp64 [nq][dim]), q_dev (fp32 [nq][dim], this device) and items (stored rows); enqueued on the handle's
+ * stream -- and the merge of `world` such messages laid end to end in device memory (host results, waits).
+ */
+int64_t morna_exact_packed_bytes(int64_t nq, int32_t k);
+int morna_exact_search_packed(morna_index *h, const double *q, const float *q_dev, const int32_t *items, int64_t nq, int32_t k,
+                              int64_t id_offset, uint8_t *packed_dev);
+int morna_merge_exact_packed(morna_index *h, const uint8_t *gathered_dev, int32_t world, int64_t nq, int32_t kk, int32_t k,
+                             int32_t *ids_out, double *dist_out, int32_t *count_out);
 
 /* ---- persistence (stands in for AnnoyIndex.save / load)      morna.py:439, 544 */
 int morna_save(morna_index *h, const char *path);

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("MORNA_LIB") or os.path.join(os.path.dirname(os.path.a
 OK, E_INVALID, E_HIP, E_STATE, E_RANGE, E_IO, E_EMPTY = 0, -1, -2, -3, -4, -5, -6
 
 T_FEATURES, T_TWO_MEANS, T_SPLIT, T_PARTITION, T_QUERY, T_EXACT, T_QUERY_FILTER, T_EXACT_SCAN = range(8)
+COMM_ID_BYTES = 128
 TIMER_NAMES = ["features", "two_means", "split", "partition", "query", "exact", "query_filter", "exact_scan"]
 
 
@@ -67,6 +68,18 @@ SIGNATURES = {
     "morna_get_nns_by_vector": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "morna_get_nns_by_item": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "morna_exact_search": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p]),
+    "morna_exact_search_by_item": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p]),
+    "morna_comm_unique_id": (C.c_int, [_p]),
+    "morna_comm_init": (C.c_int, [_p, _p, _i32, _i32]),
+    "morna_comm_destroy": (C.c_int, [_p]),
+    "morna_comm_info": (C.c_int, [_p, C.POINTER(_i32), C.POINTER(_i32), _p]),
+    "morna_get_nns_by_vector_sharded": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p, _p]),
+    "morna_get_nns_by_item_sharded": (C.c_int, [_p, _p, _i64, _p, _i32, _i32, _p, _p, _p]),
+    "morna_exact_search_sharded": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p]),
+    "morna_exact_search_by_item_sharded": (C.c_int, [_p, _p, _i64, _p, _i32, _p, _p, _p]),
+    "morna_exact_packed_bytes": (_i64, [_i64, _i32]),
+    "morna_exact_search_packed": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i64, _p]),
+    "morna_merge_exact_packed": (C.c_int, [_p, _p, _i32, _i64, _i32, _i32, _p, _p, _p]),
     "morna_save": (C.c_int, [_p, C.c_char_p]),
     "morna_load": (C.c_int, [_p, C.c_char_p]),
     "morna_timer_enable": (C.c_int, [_p, _i32]),

@@ -227,6 +227,119 @@ class AnnoyIndex(object):
         check(lib().morna_exact_search(self._h, ptr(Q), nq, int(n), ptr(ids), ptr(d), ptr(cnt)))
         return ids, d, cnt
 
+    def exact_search_by_item_batch(self, items, n):
+        """exact_search_nn for stored rows as the queries (morna_exact_search_by_item): only the item numbers are sent."""
+        items = np.ascontiguousarray(items, dtype=np.int32)
+        nq = items.shape[0]
+        ids = np.empty((nq, n), np.int32)
+        d = np.empty((nq, n), np.float64)
+        cnt = np.empty(nq, np.int32)
+        check(lib().morna_exact_search_by_item(self._h, ptr(items), nq, int(n), ptr(ids), ptr(d), ptr(cnt)))
+        return ids, d, cnt
+
+    # ---- row-sharded search, communicator inside the library (comm.hip) --------
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes from ncclGetUniqueId: made by ONE rank and handed to the others by the caller."""
+        out = np.zeros(_lib.COMM_ID_BYTES, np.uint8)
+        check(lib().morna_comm_unique_id(ptr(out)))
+        return out.tobytes()
+
+    def comm_init(self, unique_id, rank, world):
+        uid = np.frombuffer(bytes(unique_id), np.uint8).copy()
+        if len(uid) != _lib.COMM_ID_BYTES:
+            raise ValueError("a communicator id has %d bytes" % _lib.COMM_ID_BYTES)
+        check(lib().morna_comm_init(self._h, ptr(uid), int(rank), int(world)))
+
+    def comm_destroy(self):
+        check(lib().morna_comm_destroy(self._h))
+
+    def comm_info(self, offsets=True):
+        """(rank, world, offsets[world + 1] or None); asking for the offsets is a collective."""
+        r, w = C.c_int32(), C.c_int32()
+        check(lib().morna_comm_info(self._h, C.byref(r), C.byref(w), None))
+        off = None
+        if offsets:
+            off = np.zeros(w.value + 1, np.int64)
+            check(lib().morna_comm_info(self._h, C.byref(r), C.byref(w), ptr(off)))
+        return r.value, w.value, off
+
+    def get_nns_by_vector_sharded(self, Q, n, search_k=-1):
+        """Q: [nq, f] fp32 (host array) or (device pointer, nq); the same on every rank.  Merged global ids."""
+        if isinstance(Q, tuple):
+            q_ptr, nq = C.c_void_p(int(Q[0])), int(Q[1])
+        else:
+            Q = np.ascontiguousarray(Q, dtype=np.float32)
+            q_ptr, nq = ptr(Q), Q.shape[0]
+        ids = np.empty((nq, n), np.int32)
+        d = np.empty((nq, n), np.float32)
+        cnt = np.empty(nq, np.int32)
+        check(lib().morna_get_nns_by_vector_sharded(self._h, q_ptr, nq, int(n), int(search_k), ptr(ids), ptr(d), ptr(cnt)))
+        return ids, d, cnt
+
+    def get_nns_by_item_sharded(self, local_items, n, search_k=-1, n_each=None):
+        """Every rank's own items as queries; answers for all ranks' queries (rank 0's first).  n_each: every rank's
+        query count -- the output arrays are sized from it (the C entry point can exchange the counts itself; a caller
+        that does not know them all-gathers them first, as dist.ShardedSearch does)."""
+        items = np.ascontiguousarray(local_items, dtype=np.int32)
+        if n_each is None:
+            if self.comm_info(offsets=False)[1] != 1:
+                raise ValueError("n_each (every rank's query count) is required when there is more than one rank")
+            n_each = [len(items)]
+        n_each = np.ascontiguousarray(n_each, dtype=np.int64)
+        nq = int(n_each.sum())
+        ids = np.empty((nq, n), np.int32)
+        d = np.empty((nq, n), np.float32)
+        cnt = np.empty(nq, np.int32)
+        check(lib().morna_get_nns_by_item_sharded(self._h, ptr(items), len(items), ptr(n_each), int(n), int(search_k),
+                                                  ptr(ids), ptr(d), ptr(cnt)))
+        return ids, d, cnt
+
+    def exact_search_sharded(self, Q, n):
+        Q = np.ascontiguousarray(Q, dtype=np.float64)
+        nq = Q.shape[0]
+        ids = np.empty((nq, n), np.int32)
+        d = np.empty((nq, n), np.float64)
+        cnt = np.empty(nq, np.int32)
+        check(lib().morna_exact_search_sharded(self._h, ptr(Q), nq, int(n), ptr(ids), ptr(d), ptr(cnt)))
+        return ids, d, cnt
+
+    def exact_search_by_item_sharded(self, local_items, n, n_each):
+        items = np.ascontiguousarray(local_items, dtype=np.int32)
+        n_each = np.ascontiguousarray(n_each, dtype=np.int64)
+        nq = int(n_each.sum())
+        ids = np.empty((nq, n), np.int32)
+        d = np.empty((nq, n), np.float64)
+        cnt = np.empty(nq, np.int32)
+        check(lib().morna_exact_search_by_item_sharded(self._h, ptr(items), len(items), ptr(n_each), int(n),
+                                                       ptr(ids), ptr(d), ptr(cnt)))
+        return ids, d, cnt
+
+    @staticmethod
+    def exact_packed_bytes(nq, n):
+        return int(lib().morna_exact_packed_bytes(int(nq), int(n)))
+
+    def exact_search_packed(self, packed_ptr, n, id_offset, Q=None, q_dev=None, items=None):
+        """Per-shard exact answers packed in HBM at packed_ptr (exact_packed_bytes(nq, n) bytes), enqueued."""
+        qp = dp = ip = None
+        if Q is not None:
+            Q = np.ascontiguousarray(Q, dtype=np.float64)
+            qp, nq = ptr(Q), Q.shape[0]
+        elif q_dev is not None:
+            dp, nq = C.c_void_p(int(q_dev[0])), int(q_dev[1])
+        else:
+            items = np.ascontiguousarray(items, dtype=np.int32)
+            ip, nq = ptr(items), len(items)
+        check(lib().morna_exact_search_packed(self._h, qp, dp, ip, nq, int(n), int(id_offset), C.c_void_p(int(packed_ptr))))
+
+    def merge_exact_packed(self, gathered_ptr, world, nq, kk, n):
+        ids = np.empty((nq, n), np.int32)
+        d = np.empty((nq, n), np.float64)
+        cnt = np.empty(nq, np.int32)
+        check(lib().morna_merge_exact_packed(self._h, C.c_void_p(int(gathered_ptr)), int(world), int(nq), int(kk), int(n),
+                                             ptr(ids), ptr(d), ptr(cnt)))
+        return ids, d, cnt
+
     # ---- persistence ---------------------------------------------------------
     def save(self, fn):
         check(lib().morna_save(self._h, str(fn).encode()))

@@ -62,7 +62,7 @@ def build(force=False, verbose=False):
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]   # zlib: parse.hip
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz", "-ldl"]   # zlib: parse.hip; dl: RCCL is looked up at run time (comm.hip)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -148,6 +148,7 @@ int morna_index_destroy(morna_index *h)
     if (!h) return MORNA_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)morna_comm_destroy(h);
     for (const PendingEv &pe : h->pending_ev) {
         (void)hipEventDestroy(pe.a);
         (void)hipEventDestroy(pe.b);
@@ -399,6 +400,8 @@ static int get_item_vectors_impl(morna_index *h, const int32_t *ids, int64_t n, 
     if (wait) {
         HIP_TRY(hipMemcpyAsync(out, d_rows, (size_t)n * h->dim * 4, hipMemcpyDefault, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+    } else {
+        h->unsettled = true;   // returns with work queued
     }
     return MORNA_OK;
 }
@@ -519,6 +522,7 @@ int morna_get_nns_by_vector_packed(morna_index *h, const float *q, int64_t nq, i
         return MORNA_E_RANGE;
     }
     HIP_TRY(hipSetDevice(h->device));
+    h->unsettled = true;   // returns with work queued: blocking copies on the null stream must settle() first
     return query_batch(h, q, 0, nullptr, nq, k, search_k, nullptr, nullptr, nullptr, packed_dev, id_offset);
 }
 
@@ -668,6 +672,7 @@ static int load_impl(morna_index *h, const char *path, FILE *f)
     h->host_rows.clear(); h->host_n = 0; h->host_dirty = false; h->built = false;
     h->half_valid = false;
     h->n_items = hd.n_items;
+    h->comm_sizes_valid = false;
     MORNA_TRY(h->X.alloc((size_t)std::max<int64_t>(hd.n_items, 1) * h->dpad));
     (void)hipMemset(h->X.p, 0, (size_t)std::max<int64_t>(hd.n_items, 1) * h->dpad * 4);
     if (hd.n_items > 0) {
@@ -740,6 +745,7 @@ int morna_load(morna_index *h, const char *path)
     if (rc != MORNA_OK) {   // a failed load leaves an empty, unbuilt index rather than half of one
         h->built = false;
         h->n_items = 0;
+        h->comm_sizes_valid = false;
         h->norms_valid = false;
     }
     return rc;

@@ -180,11 +180,23 @@ struct morna_index {
 
     // query workspace (grown on demand)
     morna::DevBuf<uint8_t> ws;
+    // exact search: query images, scan values and results of a batch; the candidates and their fp64 distances (knn.hip)
+    morna::DevBuf<uint8_t> ex_ws;
+    morna::DevBuf<int32_t> ex_cand;
+    morna::DevBuf<double> ex_cdist;
+    int32_t ex_cap = 0;                // candidates per query the last exact search needed room for
     // build scratch kept between calls (feature and forest builds reuse it instead of
     // hipMalloc / hipFree on every call); slots are named in features.hip / forest.hip
     morna::DevBuf<uint8_t> scratch[35];
     // [0] rows read by query kernels (hyperplane dots + candidates + 1 per query)
     morna::DevBuf<unsigned long long> d_stat;
+
+    // row-sharded search (comm.hip): the RCCL communicator of this shard, every shard's first global id, message buffers
+    void *comm = nullptr;              // ncclComm_t
+    int32_t comm_rank = 0, comm_world = 1;
+    bool comm_sizes_valid = false;     // comm_offsets describe the rows the ranks hold NOW (cleared whenever this handle's rows change)
+    std::vector<int64_t> comm_offsets; // [world + 1]
+    morna::DevBuf<uint8_t> cm_small, cm_msg, cm_q, cm_out;
 
     // timing
     bool timing = false;
@@ -259,5 +271,10 @@ int merge_topk_dev(morna_index *h, const int32_t *gathered_dev, int32_t world, i
                    int32_t *ids_out, float *dist_out, int32_t *count_out);
 int exact_search(morna_index *h, const double *q, int64_t nq, int32_t k, int32_t *ids_out,
                  double *dist_out, int32_t *count_out);
+// the same for fp32 queries in device memory or for stored rows, answers to the host and / or packed for the sharded merge
+int exact_search_any(morna_index *h, const double *q_host, const float *q_dev, const int32_t *items_host, int64_t nq, int32_t k,
+                     int32_t *ids_out, double *dist_out, int32_t *count_out, uint8_t *msg_dev, int64_t id_offset);
+size_t exact_msg_dist_offset(int64_t nq, int32_t k);
+size_t exact_msg_bytes(int64_t nq, int32_t k);
 
 }  // namespace morna

@@ -805,6 +805,7 @@ int upload_host_rows(morna_index *h)
                                  (size_t)h->dim * sizeof(float), (size_t)h->dim * sizeof(float), (size_t)n,
                                  hipMemcpyHostToDevice, h->stream));
     h->n_items = n;
+    h->comm_sizes_valid = false;
     h->host_dirty = false;
     h->built = false;
     MORNA_TRY(compute_norms(h));
@@ -973,6 +974,7 @@ int build_features(morna_index *h, int64_t n_items)
         }
         HIP_TRY(hipGetLastError());
         h->n_items = n_items;
+        h->comm_sizes_valid = false;
         h->host_n = 0;
         h->host_rows.clear();
         h->host_dirty = false;

@@ -979,6 +979,104 @@ __global__ __launch_bounds__(RR_THREADS) void exact_rerank_kernel(const float *_
     if (tid == 0) count_out[qi] = s_nan ? -1 : kout;
 }
 
+// Selection for shards of more than 8192 rows: TWO passes over a query's scan values instead of k (the k rounds of
+// exact_select_kernel read 4 * N * k bytes per query: 200 GB for configs[4]'s 50 000 queries x 50 000 rows, k = 20).
+//   A  every thread takes the minimum of its strided share; the kk-th smallest of the 256 minima bounds the kk-th smallest
+//      value from above (kk distinct elements lie at or below it);
+//   B  everything within eps of that bound is collected as (key, id) pairs -- a superset of the candidates;
+//   C  the kk-th smallest of the collected pairs, by counting, IS the kk-th smallest of all values: thr = it + eps;
+//   D  the candidates are the collected pairs at or below thr -- the set exact_select_kernel produces.
+// `pairs` is the memory of the re-rank's distance array (not yet in use).  More collected than `cap`: the count is reported
+// and the host retries with room for all of them, as for the candidates themselves.  Needs k <= 256 (one minimum per thread).
+__global__ __launch_bounds__(256) void exact_select2_kernel(const float *__restrict__ approx, int64_t n_items, int32_t k, float eps,
+                                                            int32_t cap, uint2 *__restrict__ pairs /* [nq][cap] */,
+                                                            int32_t *__restrict__ cand /* [nq][cap] */,
+                                                            int32_t *__restrict__ ncand_out /* [nq] */)
+{
+    __shared__ uint64_t s_key[256];
+    __shared__ int s_n;
+    __shared__ uint32_t s_thr;
+    const int tid = threadIdx.x;
+    const int64_t qi = blockIdx.x;
+    const float *a = approx + qi * n_items;
+    const int kk = (int)(k < n_items ? k : n_items);
+    uint64_t mine = ~0ull;
+    for (int64_t i = tid; i < n_items; i += 256) {
+        const uint64_t key = ((uint64_t)f32_orderable(a[i]) << 32) | (uint32_t)i;
+        mine = key < mine ? key : mine;
+    }
+    s_key[tid] = mine;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    {
+        int below = 0;
+        for (int j = 0; j < 256; j++) below += s_key[j] < mine ? 1 : 0;
+        if (mine != ~0ull && below == kk - 1) s_thr = (uint32_t)(mine >> 32);
+    }
+    __syncthreads();
+    const float bound = f32_from_orderable(s_thr) + eps;
+    uint2 *pr = pairs + qi * cap;
+    for (int64_t i = tid; i < n_items; i += 256) {
+        const float v = a[i];
+        if (v <= bound) {
+            const int slot = atomicAdd(&s_n, 1);
+            if (slot < cap) pr[slot] = make_uint2(f32_orderable(v), (uint32_t)i);
+        }
+    }
+    __syncthreads();
+    const int m = s_n;
+    if (m > cap) {
+        if (tid == 0) ncand_out[qi] = m;
+        return;
+    }
+    for (int t = tid; t < m; t += 256) {
+        const uint2 p = pr[t];
+        const uint64_t kt = ((uint64_t)p.x << 32) | p.y;
+        int below = 0;
+        for (int u = 0; u < m; u++) {
+            const uint2 o = pr[u];
+            below += (((uint64_t)o.x << 32) | o.y) < kt ? 1 : 0;
+        }
+        if (below == kk - 1) s_thr = p.x;
+    }
+    __syncthreads();
+    const float thr = f32_from_orderable(s_thr) + eps;
+    __syncthreads();
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    for (int t = tid; t < m; t += 256) {
+        const uint2 p = pr[t];
+        if (f32_from_orderable(p.x) <= thr) cand[qi * cap + atomicAdd(&s_n, 1)] = (int32_t)p.y;
+    }
+    __syncthreads();
+    if (tid == 0) ncand_out[qi] = s_n;
+}
+
+// The query of exact_search_nn when it is a STORED row (or an fp32 row handed over in device memory): the fp32 values
+// widened to fp64 -- what `zip(self.annoy_index.get_item_vector(i), query)` sees when the query came out of the index
+// (morna.py:697-703).  One workgroup per query; src_stride floats between rows, items == null: row q.
+__global__ void exact_widen_kernel(const float *__restrict__ src, int64_t src_stride, const int32_t *__restrict__ items,
+                                   int32_t dim, double *__restrict__ Qd)
+{
+    const int64_t q = blockIdx.x;
+    const float *row = src + (items ? (int64_t)items[q] : q) * src_stride;
+    for (int z = threadIdx.x; z < dim; z += blockDim.x) Qd[q * dim + z] = (double)row[z];
+}
+
+// a batch's exact answers -> their place in the message of the row-sharded exact search (global ids)
+__global__ void exact_pack_kernel(const int32_t *__restrict__ ids, const double *__restrict__ dist, const int32_t *__restrict__ cnt,
+                                  int64_t nb, int32_t k, int32_t id_offset, int32_t *__restrict__ m_ids, int32_t *__restrict__ m_cnt,
+                                  double *__restrict__ m_dist)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nb * k) {
+        const int32_t id = ids[i];
+        m_ids[i] = id >= 0 ? id + id_offset : -1;
+        m_dist[i] = dist[i];
+    }
+    if (i < nb) m_cnt[i] = cnt[i];
+}
+
 // fp64 query -> fp32 image + its squared norm (selection pass only)
 __global__ void exact_prep_kernel(const double *__restrict__ Qd, int64_t nq, int32_t dim, int32_t dpad,
                                   float *__restrict__ Qf, float *__restrict__ qn2)
@@ -1141,8 +1239,16 @@ static void launch_exact_scan(morna_index *h, int64_t N, int64_t nb, const float
                        h->norm2.p, N, h->dpad, Qf, qn2, nb, approx);
 }
 
-int exact_search(morna_index *h, const double *q, int64_t nq, int32_t k, int32_t *ids_out, double *dist_out,
-                 int32_t *count_out)
+// Message of the row-sharded exact search, nq queries: ids int32 [nq][k] (global, -1 = empty) | count int32 [nq] (-1: the
+// reference raises for this query) | pad to 8 bytes | distances fp64 [nq][k]
+size_t exact_msg_dist_offset(int64_t nq, int32_t k) { return align_up((size_t)nq * ((size_t)k + 1) * 4, 8); }
+size_t exact_msg_bytes(int64_t nq, int32_t k) { return exact_msg_dist_offset(nq, k) + (size_t)nq * k * 8; }
+
+// The queries: q_host fp64 [nq][dim] (host), or q_dev fp32 [nq][dim] (this device's memory), or stored rows items_host.
+// The answers: host arrays, and / or msg_dev (device memory, exact_msg_bytes(nq, k)) with global ids = local + id_offset --
+// then only enqueued on the handle's stream behind the last selection.
+int exact_search_any(morna_index *h, const double *q_host, const float *q_dev, const int32_t *items_host, int64_t nq, int32_t k,
+                     int32_t *ids_out, double *dist_out, int32_t *count_out, uint8_t *msg_dev, int64_t id_offset)
 {
     MORNA_TRY(upload_host_rows(h));
     if (h->n_items <= 0) {
@@ -1156,6 +1262,12 @@ int exact_search(morna_index *h, const double *q, int64_t nq, int32_t k, int32_t
     if (nq == 0) return MORNA_OK;
     const int64_t N = h->n_items;
     const int32_t D = h->dim, dpad = h->dpad;
+    if (items_host)
+        for (int64_t i = 0; i < nq; i++)
+            if (items_host[i] < 0 || items_host[i] >= N) {
+                set_error("Item index %d out of range [0, %lld)", items_host[i], (long long)N);
+                return MORNA_E_RANGE;
+            }
     // queries resident per pass: their fp32 images share 64 KiB of LDS
     const int qt = (size_t)dpad * 4 * 8 <= 65536 ? 8 : (size_t)dpad * 4 * 4 <= 65536 ? 4
                    : (size_t)dpad * 4 * 2 <= 65536 ? 2 : 1;
@@ -1163,65 +1275,107 @@ int exact_search(morna_index *h, const double *q, int64_t nq, int32_t k, int32_t
         set_error("exact search: dimension %d does not fit LDS", D);
         return MORNA_E_INVALID;
     }
-    // queries per batch: approx[nq][N] floats capped at 2 GiB
+    // queries per batch: approx[nq][N] floats capped at 2 GiB.  The workspace stays with the handle (a hipMalloc / hipFree
+    // pair per array and call cost more than a small search)
     const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)1 << 29) / std::max<int64_t>(N, 1)));
-    DevBuf<double> Qd, cdist, d_dist;
-    DevBuf<float> Qf, qn2, approx;
-    DevBuf<int32_t> cand, ncand, d_ids, d_cnt;
+    const size_t s_qd = align_up((size_t)batch * D * 8, 256), s_qf = align_up((size_t)batch * dpad * 4, 256),
+                 s_b4 = align_up((size_t)batch * 4, 256), s_ap = align_up((size_t)batch * N * 4, 256),
+                 s_ids = align_up((size_t)batch * k * 4, 256), s_dist = align_up((size_t)batch * k * 8, 256);
+    MORNA_TRY(h->ex_ws.alloc(s_qd + s_qf + 4 * s_b4 + s_ap + s_ids + s_dist));
+    uint8_t *p = h->ex_ws.p;
+    double *Qd = (double *)p; p += s_qd;
+    float *Qf = (float *)p; p += s_qf;
+    float *qn2 = (float *)p; p += s_b4;
+    int32_t *ncand = (int32_t *)p; p += s_b4;
+    int32_t *d_items = (int32_t *)p; p += s_b4;
+    float *approx = (float *)p; p += s_ap;
+    uint8_t *const out_block = p;   // ids, distances, counts: one block, one copy to the host
+    int32_t *d_ids = (int32_t *)p; p += s_ids;
+    double *d_dist = (double *)p; p += s_dist;
+    int32_t *d_cnt = (int32_t *)p; p += s_b4;
     std::vector<int32_t> h_ncand((size_t)batch);
-    int32_t cap = std::max(64, 4 * k);
-    MORNA_TRY(Qd.alloc((size_t)batch * D));
-    MORNA_TRY(Qf.alloc((size_t)batch * dpad));
-    MORNA_TRY(qn2.alloc((size_t)batch));
-    MORNA_TRY(approx.alloc((size_t)batch * N));
-    MORNA_TRY(ncand.alloc((size_t)batch));
-    MORNA_TRY(d_ids.alloc((size_t)batch * k));
-    MORNA_TRY(d_dist.alloc((size_t)batch * k));
-    MORNA_TRY(d_cnt.alloc((size_t)batch));
+    int32_t cap = std::max<int32_t>(std::max(64, 4 * k), h->ex_cap);
     for (int64_t q0 = 0; q0 < nq; q0 += batch) {
         const int64_t nb = std::min(batch, nq - q0);
-        HIP_TRY(hipMemcpyAsync(Qd.p, q + q0 * D, (size_t)nb * D * 8, hipMemcpyHostToDevice, h->stream));
+        if (q_host) {
+            HIP_TRY(hipMemcpyAsync(Qd, q_host + q0 * D, (size_t)nb * D * 8, hipMemcpyHostToDevice, h->stream));
+        } else if (q_dev) {
+            hipLaunchKernelGGL(exact_widen_kernel, dim3((unsigned)nb), dim3(256), 0, h->stream, q_dev + q0 * D, (int64_t)D, nullptr, D, Qd);
+        } else {
+            HIP_TRY(hipMemcpyAsync(d_items, items_host + q0, (size_t)nb * 4, hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(exact_widen_kernel, dim3((unsigned)nb), dim3(256), 0, h->stream, h->X.p, (int64_t)dpad, d_items, D, Qd);
+        }
         {
             // one pass over the matrix per qt queries: 4*D*N bytes each
             const int64_t q_per_pass = nb >= 32 ? MM_TILE : qt;
             ScopedTimer tm(h, MORNA_T_EXACT, 4 * (int64_t)D * N * ((nb + q_per_pass - 1) / q_per_pass));
             hipLaunchKernelGGL(exact_prep_kernel, dim3((unsigned)((nb * WAVE + 255) / 256)), dim3(256), 0, h->stream,
-                               Qd.p, nb, D, dpad, Qf.p, qn2.p);
+                               Qd, nb, D, dpad, Qf, qn2);
             ScopedTimer ts(h, MORNA_T_EXACT_SCAN, nb >= 32 ? 2 * (int64_t)nb * N * dpad : 0);   // "bytes" = flops on the matrix cores
             if (nb >= 32) {   // enough queries to fill MFMA tiles: dense contraction on the matrix cores
                 dim3 grid((unsigned)((N + MM_TILE - 1) / MM_TILE), (unsigned)((nb + MM_TILE - 1) / MM_TILE));
-                hipLaunchKernelGGL(exact_scan_mfma_kernel, grid, dim3(256), 0, h->stream, h->X.p, h->norm2.p, N, dpad, Qf.p,
-                                   qn2.p, nb, approx.p);
-            } else if (qt == 8) launch_exact_scan<8>(h, N, nb, Qf.p, qn2.p, approx.p);
-            else if (qt == 4) launch_exact_scan<4>(h, N, nb, Qf.p, qn2.p, approx.p);
-            else if (qt == 2) launch_exact_scan<2>(h, N, nb, Qf.p, qn2.p, approx.p);
-            else launch_exact_scan<1>(h, N, nb, Qf.p, qn2.p, approx.p);
+                hipLaunchKernelGGL(exact_scan_mfma_kernel, grid, dim3(256), 0, h->stream, h->X.p, h->norm2.p, N, dpad, Qf,
+                                   qn2, nb, approx);
+            } else if (qt == 8) launch_exact_scan<8>(h, N, nb, Qf, qn2, approx);
+            else if (qt == 4) launch_exact_scan<4>(h, N, nb, Qf, qn2, approx);
+            else if (qt == 2) launch_exact_scan<2>(h, N, nb, Qf, qn2, approx);
+            else launch_exact_scan<1>(h, N, nb, Qf, qn2, approx);
         }
         HIP_TRY(hipGetLastError());
         const float eps = exact_scan_eps(dpad, nb >= 32);   // which scan ran
         ScopedTimer tm_sel(h, MORNA_T_EXACT, 0);            // selection + fp64 re-rank: the same group as the scan
+        static const bool select2_on = !(getenv("MORNA_EXACT_SELECT2") && atoi(getenv("MORNA_EXACT_SELECT2")) == 0);
         for (;;) {
-            MORNA_TRY(cand.alloc((size_t)batch * cap));
-            MORNA_TRY(cdist.alloc((size_t)batch * cap));
-            hipLaunchKernelGGL(exact_select_kernel, dim3((unsigned)nb), dim3(256), 0, h->stream, approx.p, N, k, eps,
-                               cap, cand.p, ncand.p);
+            MORNA_TRY(h->ex_cand.alloc((size_t)batch * cap));
+            MORNA_TRY(h->ex_cdist.alloc((size_t)batch * cap));
+            if (N > 8192 && k <= 256 && select2_on)
+                hipLaunchKernelGGL(exact_select2_kernel, dim3((unsigned)nb), dim3(256), 0, h->stream, approx, N, k, eps, cap,
+                                   (uint2 *)h->ex_cdist.p, h->ex_cand.p, ncand);
+            else
+                hipLaunchKernelGGL(exact_select_kernel, dim3((unsigned)nb), dim3(256), 0, h->stream, approx, N, k, eps,
+                                   cap, h->ex_cand.p, ncand);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(h_ncand.data(), ncand.p, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipMemcpyAsync(h_ncand.data(), ncand, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
             int32_t need = 0;
             for (int64_t i = 0; i < nb; i++) need = std::max(need, h_ncand[(size_t)i]);
             if (need <= cap) break;
             cap = need;   // huge tie groups at the boundary: make room for all of them
         }
+        h->ex_cap = cap;   // the next call starts with the room this one needed
         hipLaunchKernelGGL(exact_rerank_kernel, dim3((unsigned)nb), dim3(RR_THREADS), 0, h->stream, h->X.p, D, dpad,
-                           Qd.p, cand.p, ncand.p, cap, k, cdist.p, d_ids.p, d_dist.p, d_cnt.p);
+                           Qd, h->ex_cand.p, ncand, cap, k, h->ex_cdist.p, d_ids, d_dist, d_cnt);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(ids_out + q0 * k, d_ids.p, (size_t)nb * k * 4, hipMemcpyDeviceToHost, h->stream));
-        if (dist_out) HIP_TRY(hipMemcpyAsync(dist_out + q0 * k, d_dist.p, (size_t)nb * k * 8, hipMemcpyDeviceToHost, h->stream));
-        if (count_out) HIP_TRY(hipMemcpyAsync(count_out + q0, d_cnt.p, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (msg_dev) {
+            hipLaunchKernelGGL(exact_pack_kernel, dim3((unsigned)((nb * k + 255) / 256)), dim3(256), 0, h->stream, d_ids, d_dist, d_cnt,
+                               nb, k, (int32_t)id_offset, (int32_t *)msg_dev + q0 * k, (int32_t *)msg_dev + nq * k + q0,
+                               (double *)(msg_dev + exact_msg_dist_offset(nq, k)) + q0 * k);
+            HIP_TRY(hipGetLastError());
+            h->unsettled = true;
+        }
+        if (ids_out) {
+            const size_t out_bytes = s_ids + s_dist + s_b4;
+            if (out_bytes > h->host_out_cap) {
+                if (h->host_out) (void)hipHostFree(h->host_out);
+                h->host_out = nullptr;
+                h->host_out_cap = 0;
+                HIP_TRY(hipHostMalloc((void **)&h->host_out, out_bytes * 2, hipHostMallocDefault));
+                h->host_out_cap = out_bytes * 2;
+            }
+            HIP_TRY(hipMemcpyAsync(h->host_out, out_block, out_bytes, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            memcpy(ids_out + q0 * k, h->host_out, (size_t)nb * k * 4);
+            if (dist_out) memcpy(dist_out + q0 * k, h->host_out + s_ids, (size_t)nb * k * 8);
+            if (count_out) memcpy(count_out + q0, h->host_out + s_ids + s_dist, (size_t)nb * 4);
+        }
     }
     return MORNA_OK;
+}
+
+int exact_search(morna_index *h, const double *q, int64_t nq, int32_t k, int32_t *ids_out, double *dist_out,
+                 int32_t *count_out)
+{
+    return exact_search_any(h, q, nullptr, nullptr, nq, k, ids_out, dist_out, count_out, nullptr, 0);
 }
 
 }  // namespace morna

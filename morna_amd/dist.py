@@ -9,8 +9,6 @@ over xGMI -- after which every rank holds the merged (distance, id)-ordered top 
 `torch.distributed` with backend "nccl" is RCCL on ROCm; "gloo" is used by the
 CPU tests with a stand-in local index.
 """
-import contextlib
-
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -20,18 +18,45 @@ from .shards import merge_topk, merge_topk_exact, merge_topk_native   # noqa: E4
 
 
 class ShardedSearch(object):
-    """index: the local shard (AnnoyIndex-shaped: get_nns_by_vector_batch,
-    get_item_vectors).  Global id = offset[rank] + local id."""
+    """index: the local shard (AnnoyIndex-shaped).  Global id = offset[rank] + local id.
+
+    Backend "nccl" (the product path): the exchange runs INSIDE libmorna_hip -- the handle owns an RCCL communicator
+    (morna_comm_init), per-shard search, ncclAllGather and merge kernel are enqueued on the handle's stream, and this class
+    only forwards; torch.distributed is used once, to hand rank 0's communicator id to the other ranks.  Backend "gloo"
+    (CPU tests with a stand-in index; rehearsals of N ranks on fewer GPUs): per-shard answers through the host, gloo
+    all-gather, host merge -- the same merges (shards.py), so both paths give one answer."""
 
     def __init__(self, index, rank, world, n_local, group=None):
         self.index, self.rank, self.world, self.group = index, rank, world, group
+        self.in_library = dist.get_backend(group) == "nccl" and hasattr(index, "comm_init")
         self.device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" \
             else torch.device("cpu")
-        sizes = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([n_local], dtype=torch.int64, device=self.device), group=group)
-        self.sizes = [int(s.item()) for s in sizes]
+        if self.in_library:
+            try:                                   # a communicator from an earlier ShardedSearch over this handle
+                have = index.comm_info(offsets=False)[:2]
+            except RuntimeError:
+                have = None
+            if have != (rank, world):
+                if have is not None:
+                    index.comm_destroy()
+                uid = [index.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0, group=group, device=self.device)
+                index.comm_init(uid[0], rank, world)
+            self.sizes = np.diff(index.comm_info()[2]).tolist()
+        else:
+            sizes = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(world)]
+            dist.all_gather(sizes, torch.tensor([n_local], dtype=torch.int64, device=self.device), group=group)
+            self.sizes = [int(s.item()) for s in sizes]
+        if self.sizes[rank] != n_local:
+            raise ValueError("shard %d holds %d items, the caller says %d" % (rank, self.sizes[rank], n_local))
         self.offsets = np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int64)
         self.n_total = int(self.offsets[-1])
+
+    def close(self):
+        """Give the library's communicator back (before the process group goes)."""
+        if self.in_library:
+            self.index.comm_destroy()
+            self.in_library = False
 
     def _all_gather_np(self, a):
         t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
@@ -39,10 +64,12 @@ class ShardedSearch(object):
         dist.all_gather(outs, t, group=self.group)
         return np.stack([o.cpu().numpy() for o in outs])
 
+    def _global(self, ids):
+        return np.where(ids >= 0, ids.astype(np.int64) + self.offsets[self.rank], -1)
+
     def _gather_merge(self, ids, d, k):
-        """All-gather of the per-shard top-k -- the one collective on the data path -- as a single
-        [nq, 2k] int32 message per rank (global ids, then the fp32 distance bits), then the merge."""
-        gids = np.where(ids >= 0, ids.astype(np.int64) + self.offsets[self.rank], -1)
+        """(host path) all-gather of the per-shard top-k as one [nq, 2k] int32 message per rank, then the merge"""
+        gids = self._global(ids)
         if self.n_total < 2 ** 31:
             packed = np.concatenate([gids.astype(np.int32), np.ascontiguousarray(d, np.float32).view(np.int32)], axis=1)
             allp = self._all_gather_np(packed)
@@ -53,38 +80,21 @@ class ShardedSearch(object):
             all_d = self._all_gather_np(np.ascontiguousarray(d, np.float32))
         return merge_topk_native(all_ids, all_d, k)
 
-    def _device_path(self):
-        """RCCL group and a shard that can keep its answers in HBM (libmorna_hip's packed entry points)."""
-        return (self.device.type == "cuda" and hasattr(self.index, "get_nns_by_vector_packed")
-                and self.n_total < 2 ** 31 and self.world <= 64)
-
-    def _lib_stream(self):
-        """The shard's own HIP stream as a torch stream: the collectives are enqueued between the library's kernels in
-        stream order, so the host never waits between query rows, search, all-gather and merge."""
-        if getattr(self, "_ext_stream", None) is None:
-            self._ext_stream = torch.cuda.ExternalStream(self.index.stream_ptr(), device=self.device)
-        return self._ext_stream
-
-    def _search_gather_merge_dev(self, q_ptr, nq, k, search_k, keep=None):
-        """The data path of SURVEY.md 8(e) without a host hop: per-shard top-k written to HBM as one [nq, 2k] int32
-        message (global ids, distance bits), RCCL all-gather of Q*k*8 bytes per rank, merge kernel; only the merged
-        result crosses PCIe.  Everything is ordered on the library's stream; the one host wait is for the merged result.
-        keep: tensors the enqueued work reads (kept alive until it has run)."""
-        with torch.cuda.stream(self._lib_stream()):
-            packed = torch.empty((nq, 2 * k), dtype=torch.int32, device=self.device)
-            self.index.get_nns_by_vector_packed(q_ptr, nq, k, search_k, int(self.offsets[self.rank]), packed.data_ptr())
-            gathered = torch.empty((self.world, nq, 2 * k), dtype=torch.int32, device=self.device)
-            dist.all_gather_into_tensor(gathered, packed, group=self.group)
-            ids, d, cnt = self.index.merge_topk_packed(gathered.data_ptr(), self.world, nq, k, k)   # waits for the stream
-        del keep
-        return ids.astype(np.int64), d, cnt
+    def _n_each(self, n_local, n_each):
+        if n_each is None:
+            t = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(self.world)]
+            dist.all_gather(t, torch.tensor([n_local], dtype=torch.int64, device=self.device), group=self.group)
+            return [int(x.item()) for x in t]
+        if len(n_each) != self.world or n_each[self.rank] != n_local:
+            raise ValueError("n_each must list every rank's query count, this rank's being len(items)")
+        return list(n_each)
 
     def get_nns_by_vector(self, Q, k, search_k=-1):
         """Q: [nq, f] fp32, identical on every rank.  Returns merged global ids,
         distances and counts on every rank."""
-        if self._device_path() and k <= 255:
-            Q = np.ascontiguousarray(Q, dtype=np.float32)
-            return self._search_gather_merge_dev(Q.ctypes.data, Q.shape[0], k, search_k)
+        if self.in_library:
+            ids, d, cnt = self.index.get_nns_by_vector_sharded(Q, k, search_k)
+            return ids.astype(np.int64), d, cnt
         ids, d, cnt = self.index.get_nns_by_vector_batch(Q, k, search_k)
         return self._gather_merge(ids, d, k)
 
@@ -92,9 +102,13 @@ class ShardedSearch(object):
         """exact_search_nn (morna.py:681-716) over the row-sharded matrix: Q [nq, f] fp64, identical on
         every rank; per-shard exact top-k (fp64, reference order), all-gather, merge with the bisect_left
         tie rule.  Same ids and distances as one index holding all rows."""
-        ids, d, cnt = self.index.exact_search_batch(Q, k)
-        gids = np.where(ids >= 0, ids.astype(np.int64) + self.offsets[self.rank], -1)
-        all_ids = self._all_gather_np(gids)
+        if self.in_library:
+            ids, d, cnt = self.index.exact_search_sharded(Q, k)
+            return ids.astype(np.int64), d, cnt
+        return self._exact_merge(*self.index.exact_search_batch(Q, k), k=k)
+
+    def _exact_merge(self, ids, d, cnt, k):
+        all_ids = self._all_gather_np(self._global(ids))
         all_d = self._all_gather_np(np.ascontiguousarray(d, np.float64))
         out_ids, out_d, counts = merge_topk_exact(all_ids, all_d, k)
         # count -1 = "the reference raises ValueError for this query" (a row whose cosine_distance has a negative
@@ -102,42 +116,31 @@ class ShardedSearch(object):
         failed = (self._all_gather_np(np.ascontiguousarray(cnt, np.int32)) < 0).any(axis=0)
         return out_ids, out_d, np.where(failed, -1, counts).astype(np.int32)
 
+    def _gather_rows(self, items, n_each):
+        """(host path) every rank's query rows, rank 0's first: [sum n_each, f] fp32"""
+        n_max = max(n_each)
+        mine = np.zeros((n_max, self.index.f), np.float32)
+        if len(items):
+            mine[:len(items)] = self.index.get_item_vectors(items)
+        allq = self._all_gather_np(mine)               # query vectors: nq * D * 4 bytes, once
+        return np.concatenate([allq[g, :n_each[g]] for g in range(self.world)], axis=0)
+
     def get_nns_by_local_items(self, items, k, search_k=-1, n_each=None):
         """Each rank contributes the rows of some of its own items as queries
         (the by-item form, morna.py:762); every rank gets the answers to all of them,
         ordered rank 0's queries first.  n_each: how many queries each rank contributes, when the caller
         knows (saves the exchange of the counts, a latency-bound collective per call)."""
-        if n_each is None:
-            n_each = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(self.world)]
-            dist.all_gather(n_each, torch.tensor([len(items)], dtype=torch.int64, device=self.device), group=self.group)
-            n_each = [int(x.item()) for x in n_each]
-        elif len(n_each) != self.world or n_each[self.rank] != len(items):
-            raise ValueError("n_each must list every rank's query count, this rank's being len(items)")
-        n_max = max(n_each)
-        f = self.index.f
-        if self.device.type == "cuda" and hasattr(self.index, "get_nns_by_vector_ptr"):
-            # RCCL path: the query rows go HBM -> xGMI -> HBM, never through the host
-            dev_path = self._device_path() and k <= 255 and hasattr(self.index, "get_item_vectors_dev")
-            with torch.cuda.stream(self._lib_stream()) if dev_path else contextlib.nullcontext():
-                even = all(n == n_max for n in n_each)
-                mine = (torch.empty if even else torch.zeros)((n_max, f), dtype=torch.float32, device=self.device)
-                if len(items):
-                    if dev_path:
-                        self.index.get_item_vectors_dev(items, mine.data_ptr())    # in stream order, no host wait
-                    else:
-                        self.index.get_item_vectors_into(items, mine.data_ptr())   # synchronises the library's stream
-                allq = torch.empty((self.world, n_max, f), dtype=torch.float32, device=self.device)
-                dist.all_gather_into_tensor(allq, mine, group=self.group)          # query vectors: nq * D * 4 bytes, once
-                Q = allq.view(-1, f) if even else \
-                    torch.cat([allq[g, :n_each[g]] for g in range(self.world)], dim=0).contiguous()
-            if dev_path:
-                return self._search_gather_merge_dev(Q.data_ptr(), Q.shape[0], k, search_k, keep=(mine, allq, Q))
-            torch.cuda.current_stream().synchronize()                              # the library reads Q on its own stream
-            ids, d, cnt = self.index.get_nns_by_vector_ptr(Q.data_ptr(), Q.shape[0], k, search_k)
-            return self._gather_merge(ids, d, k)
-        mine = np.zeros((n_max, f), np.float32)
-        if len(items):
-            mine[:len(items)] = self.index.get_item_vectors(items)
-        allq = self._all_gather_np(mine)               # query vectors: nq * D * 4 bytes, once
-        Q = np.concatenate([allq[g, :n_each[g]] for g in range(self.world)], axis=0)
-        return self.get_nns_by_vector(Q, k, search_k)
+        n_each = self._n_each(len(items), n_each)
+        if self.in_library:
+            ids, d, cnt = self.index.get_nns_by_item_sharded(items, k, search_k, n_each=n_each)
+            return ids.astype(np.int64), d, cnt
+        return self.get_nns_by_vector(self._gather_rows(items, n_each), k, search_k)
+
+    def exact_search_by_local_items(self, items, k, n_each=None):
+        """exact_search_nn with stored rows as the queries, every rank contributing rows of its own shard (configs[4]:
+        every item of the index against the whole index): the fp32 row widened to fp64 is the query (morna.py:697-703)."""
+        n_each = self._n_each(len(items), n_each)
+        if self.in_library:
+            ids, d, cnt = self.index.exact_search_by_item_sharded(items, k, n_each)
+            return ids.astype(np.int64), d, cnt
+        return self.exact_search(self._gather_rows(items, n_each).astype(np.float64), k)

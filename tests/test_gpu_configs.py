@@ -11,8 +11,9 @@
               index, sharded exact search identical, approximate recall not worse; a 25k x 3000 shard through
               ShardedSearch on a 1-rank RCCL group (the 8-GPU run itself is the driver's; the 200k-sample set is cut by
               scripts/c4_200k_shard.py, profiles/r03_c4_200k_shard.json).
-  configs[4]  50k x 8192 exact all-pairs: one GPU's 6250-row shard, all 6250 rows as queries (morna.py:681-716
-              for every item), ids and fp64 distances against the oracle on a 64-query sample.
+  configs[4]  50k x 8192 exact all-pairs at its real size on one GPU (50 000 by-item queries x 50 000 rows, 32 sampled
+              queries bit-exact against the oracle); one GPU's share of the 8-way cut (its 6250-row shard x all 50 000
+              queries) through ShardedSearch on a 1-rank RCCL group; the 6250 x 6250 diagonal block.
 
 Parity unpinned for the forest at N > K (no reference fixture has N > K, annoy is absent): what is pinned is the
 feature matrix and the exact search; the forest is compared with this repository's restatements of annoy.
@@ -355,6 +356,99 @@ def test_c5_exact_all_pairs_shard_8192(capi):
     # the same through the few-queries path (vector-ALU scan): identical answers, whichever scan selects
     ids2, d2, _ = a.exact_search_batch(Q[:16], k)
     assert ids2.tolist() == ids[:16].tolist() and d2.tobytes() == d[:16].tobytes()
+
+
+@pytest.fixture(scope="module")
+def c5(c3):
+    """configs[4]'s matrix at its real size: the 50k-sample data set at 8192 features (1.64 GB of fp32 rows, one GPU)."""
+    from morna_amd.annoy import AnnoyIndex
+    prep = c3["prep"]
+    a = AnnoyIndex(8192)
+    a.stage_junctions(prep["key_bytes"], prep["key_off"], prep["row_ptr"], prep["ids"], prep["cov"], prep["idf"])
+    a.stage_item_order(prep["ext_ids"])
+    a.build_features(prep["n_items"])
+    a.unstage_junctions()
+    return dict(index=a, X=a.get_items(), N=prep["n_items"])
+
+
+def test_c5_exact_all_pairs_full_size_by_item_one_gpu(c5, capi):
+    """configs[4] as stated: 50k samples x 8192 features, exact brute-force k-NN of EVERY item against all items
+    (morna.py:681-716 with query_sample = the item's own row) -- 50 000 x 50 000 x 8192, on one GPU, through
+    morna_exact_search_by_item (only the item numbers cross PCIe; the library batches the queries).  32 sampled queries
+    bit-exact against the oracle (ids + fp64 distances); every query: itself first at distance 0, k results, ascending."""
+    a, X, N = c5["index"], c5["X"], c5["N"]
+    k = 20
+    items = np.arange(N, dtype=np.int32)
+    ids, d, cnt = a.exact_search_by_item_batch(items, k)
+    assert (cnt == k).all()
+    assert (ids[:, 0] == items).all() and (d[:, 0] == 0.0).all()
+    assert (np.diff(d, axis=1) >= 0).all()
+    assert all(len(set(r)) == k for r in ids[::97].tolist())
+    rng = np.random.default_rng(5)
+    for qi in rng.choice(N, 32, replace=False):
+        rid, rd = capi.exact_search(X, X[qi].astype(np.float64), k)
+        assert ids[qi].astype(np.int64).tolist() == rid.tolist(), qi
+        assert d[qi].tobytes() == rd.tobytes(), qi
+    # a batch small enough for the vector-ALU scan, and the same queries handed over as fp64 vectors: one answer
+    sub = items[:600]
+    ids2, d2, _ = a.exact_search_by_item_batch(sub[:16], k)
+    assert ids2.tolist() == ids[:16].tolist() and d2.tobytes() == d[:16].tobytes()
+    ids3, d3, _ = a.exact_search_batch(X[sub].astype(np.float64), k)         # the same queries handed over as fp64 vectors
+    assert ids3.tolist() == ids[:600].tolist() and d3.tobytes() == d[:600].tobytes()
+    c5["all_pairs"] = (ids, d)
+
+
+def test_c5_one_gpus_share_of_the_all_pairs_through_sharded_search(c3, c5, capi):
+    """configs[4] on 8 GPUs, what ONE of them does: its 6250-row shard (cut from the one data set) answers ALL 50 000
+    queries, through ShardedSearch.exact_search on a 1-rank RCCL group (per-shard exact search packed in HBM ->
+    ncclAllGather -> merge kernel, all inside the library)."""
+    import torch
+    import torch.distributed as dist
+    from morna_amd.dist import ShardedSearch
+    from morna_amd.index import ParsedLines
+    X, N = c5["X"], c5["N"]
+    k, g, world = 20, 3, 8
+    part = ParsedLines.from_arrays(c3["prep"], c3["data"]["sample_count"]).shard(g, world)
+    from morna_amd.annoy import AnnoyIndex
+    a = AnnoyIndex(8192)
+    part.stage(a)
+    a.build_features(part.n_items)
+    a.unstage_junctions()
+    off, n = part.id_offset, part.n_items
+    assert (off, n) == (18750, 6250)
+    Xs = a.get_items()
+    assert Xs.tobytes() == X[off:off + n].tobytes()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ss = ShardedSearch(a, 0, 1, n)
+        assert ss.in_library
+        ids, d, cnt = ss.exact_search(X.astype(np.float64), k)               # 50 000 queries x 6250 rows
+        assert ids.shape == (N, k) and (cnt == k).all() and (np.diff(d, axis=1) >= 0).all()
+        own = np.arange(off, off + n)
+        assert (ids[own, 0] == np.arange(n)).all() and (d[own, 0] == 0.0).all()     # a row of the shard finds itself
+        rng = np.random.default_rng(6)
+        for qi in rng.choice(N, 16, replace=False):
+            rid, rd = capi.exact_search(Xs, X[qi].astype(np.float64), k)
+            assert ids[qi].tolist() == rid.tolist() and d[qi].tobytes() == rd.tobytes(), qi
+        # by item: the shard's own rows as queries, no query vectors from the host at all
+        ids2, d2, cnt2 = ss.exact_search_by_local_items(np.arange(n, dtype=np.int32), k, n_each=[n])
+        assert ids2.tolist() == ids[own].tolist() and d2.tobytes() == d[own].tobytes()
+        ss.close()
+    finally:
+        dist.destroy_process_group()
+    if "all_pairs" in c5:
+        # the whole matrix's answer restricted to this shard's rows can only be a subsequence of the shard's own answer
+        wi, wd = c5["all_pairs"]
+        for qi in range(0, N, 997):
+            mine = [(i - off) for i in wi[qi].tolist() if off <= i < off + n]
+            assert mine == [i for i in ids[qi].tolist() if i in set(mine)]
 
 
 def test_exact_search_row_parallel_to_the_query_raises(capi, tmp_path):

@@ -167,3 +167,129 @@ def test_stream_ordered_hand_over():
     assert got[:, k:].view(np.float32).tobytes() == d.tobytes()
     with pytest.raises(IndexError):
         a.get_item_vectors_dev(np.array([5000], np.int32), rows.data_ptr())
+
+
+def test_library_communicator_one_rank_through_the_c_abi_alone():
+    """the RCCL communicator is owned by the handle.  No torch.distributed here: the id comes from
+    morna_comm_unique_id, the handle joins a 1-rank communicator, and every sharded entry point -- per-shard search ->
+    ncclAllGather -> merge kernel on the handle's stream -- returns what the plain entry point returns."""
+    from morna_amd.annoy import AnnoyIndex
+    X = _rows()
+    a = AnnoyIndex(F)
+    a.add_items(X)
+    a.build(T)
+    with pytest.raises(RuntimeError):
+        a.get_nns_by_vector_sharded(X[:3], K, -1)               # no communicator yet
+    a.comm_init(AnnoyIndex.comm_unique_id(), 0, 1)
+    with pytest.raises(RuntimeError):
+        a.comm_init(AnnoyIndex.comm_unique_id(), 0, 1)          # one communicator per handle
+    rank, world, off = a.comm_info()
+    assert (rank, world, off.tolist()) == (0, 1, [0, len(X)])
+    rng = np.random.default_rng(11)
+    items = rng.choice(len(X), 70, replace=False).astype(np.int32)
+    Q = np.ascontiguousarray(X[items] + 0.01 * rng.standard_normal((70, F)).astype(np.float32))
+    for sk in (-1, 60):
+        got, want = a.get_nns_by_vector_sharded(Q, K, sk), a.get_nns_by_vector_batch(Q, K, sk)
+        assert got[0].tolist() == want[0].tolist() and got[1].tobytes() == want[1].tobytes() and got[2].tolist() == want[2].tolist()
+        got, want = a.get_nns_by_item_sharded(items, K, sk), a.get_nns_by_item_batch(items, K, sk)
+        assert got[0].tolist() == want[0].tolist() and got[1].tobytes() == want[1].tobytes() and got[2].tolist() == want[2].tolist()
+    got, want = a.exact_search_sharded(Q.astype(np.float64), K), a.exact_search_batch(Q.astype(np.float64), K)
+    assert got[0].tolist() == want[0].tolist() and got[1].tobytes() == want[1].tobytes() and got[2].tolist() == want[2].tolist()
+    got = a.exact_search_by_item_sharded(items, K, [len(items)])
+    want = a.exact_search_batch(X[items].astype(np.float64), K)
+    by_item = a.exact_search_by_item_batch(items, K)
+    for r in (got, by_item):
+        assert r[0].tolist() == want[0].tolist() and r[1].tobytes() == want[1].tobytes() and r[2].tolist() == want[2].tolist()
+    assert a.get_nns_by_vector_sharded(X[:0], K, -1)[0].shape == (0, K)
+    with pytest.raises(ValueError):
+        a.get_nns_by_item_sharded(items, K, -1, n_each=[len(items) + 1])
+    with pytest.raises(IndexError):
+        a.exact_search_by_item_sharded(np.array([len(X)], np.int32), K, [1])
+    # the rows change -> the offsets are exchanged again
+    b = AnnoyIndex(F)
+    b.comm_init(AnnoyIndex.comm_unique_id(), 0, 1)
+    b.add_items(X[:100])
+    b.build(2)
+    assert b.comm_info()[2].tolist() == [0, 100]
+    a.comm_destroy()
+    a.comm_destroy()                                            # idempotent
+    with pytest.raises(RuntimeError):
+        a.exact_search_sharded(Q.astype(np.float64), K)
+
+
+def test_exact_packed_exchange_equals_host_merge():
+    """morna_exact_search_packed + morna_merge_exact_packed: three shards' exact answers packed in HBM, laid end to end as
+    ncclAllGather leaves them, merged on the device -- against merge_topk_exact (the host merge the gloo path uses): the
+    bisect_left tie rule across shards (equal distance: higher global id first), a shard with fewer rows than k, a query
+    for which the reference raises (count -1 on one shard fails it everywhere), queries as host fp64 / device fp32 / items."""
+    import torch
+    from morna_amd.annoy import AnnoyIndex
+    from morna_amd.dist import merge_topk_exact
+    from oracle import capi
+    X = _rows()
+    for s in range(30):                                  # rows parallel to row 7 (exactly, in binary, for powers of two)
+        X[2400 + s] = X[7] * np.float32(1.0 + 0.37 * (s + 1))
+    bounds = [0, 7, 2300, 5000]
+    rng = np.random.default_rng(9)
+    items = rng.choice(5000, 50, replace=False)
+    Q = X[items].astype(np.float64)
+    Q[1] = X[10]                                         # rows 10, 4000, 4001: one distance, three shards' worth of ids
+    bad = None
+    for cand in range(2400, 2430):                       # a query whose cosine_distance to some row has a negative radicand
+        qq = X[cand].astype(np.float64) * 1.7
+        if np.isnan([capi.cosine_distance(X[r], qq) for r in [7] + list(range(2400, 2430))]).any():
+            bad = qq
+            break
+    assert bad is not None
+    Q[2] = bad
+    k, nq = 20, len(Q)
+    dev = torch.device("cuda", 0)
+    msg = AnnoyIndex.exact_packed_bytes(nq, k)
+    assert msg == (nq * (k + 1) * 4 + 7) // 8 * 8 + nq * k * 8
+    gathered = torch.zeros((3, msg), dtype=torch.uint8, device=dev)
+    shards, host = [], []
+    for g in range(3):
+        a = AnnoyIndex(F)
+        a.add_items(X[bounds[g]:bounds[g + 1]])
+        a.exact_search_packed(gathered[g].data_ptr(), k, bounds[g], Q=Q)
+        ids, d, cnt = a.exact_search_batch(Q, k)
+        host.append((np.where(ids >= 0, ids.astype(np.int64) + bounds[g], -1), d, cnt))
+        shards.append(a)
+    for a in shards:
+        a.synchronize()
+    raw = gathered.cpu().numpy()
+    for g in range(3):                                   # the message itself
+        m = raw[g]
+        assert m[:nq * k * 4].view(np.int32).reshape(nq, k).tolist() == host[g][0].tolist()
+        assert m[nq * k * 4:nq * (k + 1) * 4].view(np.int32).tolist() == host[g][2].tolist()
+        assert m[msg - nq * k * 8:].view(np.float64).tobytes() == host[g][1].tobytes()
+    assert host[2][2][2] == -1 and host[0][2][2] >= 0    # the parallel rows live on the last shard
+    ids, d, cnt = shards[1].merge_exact_packed(gathered.data_ptr(), 3, nq, k, k)
+    wi, wd, wc = merge_topk_exact(np.stack([h[0] for h in host]), np.stack([h[1] for h in host]), k)
+    failed = np.stack([h[2] for h in host]).min(axis=0) < 0
+    ok = ~failed
+    assert ids[ok].astype(np.int64).tolist() == wi[ok].tolist() and d[ok].tobytes() == wd[ok].tobytes()
+    assert cnt.tolist() == np.where(failed, -1, wc).tolist() and cnt[2] == -1
+    assert ids[1, :3].tolist() == [4001, 4000, 10]
+    whole = AnnoyIndex(F)
+    whole.add_items(X)
+    w = whole.exact_search_batch(Q, k)
+    assert ids[ok].tolist() == w[0][ok].tolist() and d[ok].tobytes() == w[1][ok].tobytes() and cnt.tolist() == w[2].tolist()
+    ids5, d5, cnt5 = shards[0].merge_exact_packed(gathered.data_ptr(), 3, nq, k, 5)           # k smaller than the lists
+    assert ids5[ok].tolist() == ids[ok][:, :5].tolist()
+    # the same message from fp32 queries in device memory and from stored rows (queries 3.. are stored rows)
+    qd = torch.from_numpy(np.ascontiguousarray(X[items[3:]])).to(dev)
+    m2 = torch.zeros(AnnoyIndex.exact_packed_bytes(nq - 3, k), dtype=torch.uint8, device=dev)
+    m3 = torch.zeros_like(m2)
+    own = [int(i) for i in items[3:] if bounds[2] <= i < bounds[3]]
+    shards[2].exact_search_packed(m2.data_ptr(), k, bounds[2], q_dev=(qd.data_ptr(), nq - 3))
+    shards[2].synchronize()
+    ref_ids, ref_d, ref_c = shards[2].exact_search_batch(X[items[3:]].astype(np.float64), k)
+    r2 = m2.cpu().numpy()
+    assert r2[:(nq - 3) * k * 4].view(np.int32).reshape(nq - 3, k).tolist() == (ref_ids + bounds[2]).tolist()
+    m4 = torch.zeros(AnnoyIndex.exact_packed_bytes(len(own), k), dtype=torch.uint8, device=dev)
+    shards[2].exact_search_packed(m4.data_ptr(), k, bounds[2], items=np.array(own, np.int32) - bounds[2])
+    shards[2].synchronize()
+    sel = [j for j, i in enumerate(items[3:]) if bounds[2] <= i < bounds[3]]
+    assert m4.cpu().numpy()[:len(own) * k * 4].view(np.int32).reshape(len(own), k).tolist() == (ref_ids[sel] + bounds[2]).tolist()
+    del m3
