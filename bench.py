@@ -7,9 +7,14 @@ One "step" = one pass of the hot path over one batch of synthetic intropolis
 already resident in HBM: feature-hashed TF-IDF matrix build (hash, accumulate,
 fp32 convert, row norms) + 200-tree forest build + 1000 by-item queries (k=20,
 morna's default search_k=100).  Default workload = BASELINE.json configs[2]:
-50k samples x 3000 features on one GPU.  With --gpus N every rank holds its own
-50k-sample shard (weak scaling); queries are answered by every shard and merged
-by an RCCL all-gather of the per-shard top-k (no other collective on the path).
+50k samples x 3000 features.  With --gpus N (default --scaling strong) the ONE
+data set is cut into N row shards -- global idf and first-seen ids, one shard and
+one forest per GPU -- so N = 1, 2, 4, 8 all index the same 50k
+samples and answer the same 1000 queries ("at 50k x 3000; 1/2/4/8 GPU");
+--samples 200000 --gpus 8 is configs[3].  --scaling weak gives every rank a
+50k-sample data set of its own instead.  Queries are answered by every shard and
+merged by an RCCL all-gather of the per-shard top-k inside the library (no other
+collective on the path).
 
 Prints ONE JSON line (rank 0).  `value` = samples indexed per second over the
 whole step (build + queries), all ranks.  `roofline` is for the kernel group
@@ -44,7 +49,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--samples", type=int, default=50_000, help="samples per GPU")
+    ap.add_argument("--samples", type=int, default=50_000, help="samples in total (--scaling strong) / per GPU (weak)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong: ONE data set of --samples cut into row shards, one per GPU (BASELINE's 50k x 3000 at 1/2/4/8 "
+                         "GPUs; --samples 200000 --gpus 8 = configs[3]); weak: every GPU indexes its own --samples")
     ap.add_argument("--features", type=int, default=3000)
     ap.add_argument("--trees", type=int, default=200)
     ap.add_argument("--queries", type=int, default=1000)
@@ -56,7 +64,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[4] shard pass reported beside the headline")
     ap.add_argument("--cpu-trees", type=int, default=24)
     ap.add_argument("--cpu-queries", type=int, default=200)
-    ap.add_argument("--verify", action="store_true", help="check results against the exact search")
+    ap.add_argument("--verify", action="store_true",
+                    help="adds recall@k against the exact search and a digest of the exact answers to 64 of the queries "
+                         "(the same for every --gpus N under --scaling strong: one data set, one answer)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend; nccl (= RCCL) is the product path, gloo only rehearses "
                          "--gpus N on a box with fewer GPUs")
@@ -112,38 +122,83 @@ def _cpu_baseline_mt(args, capi, X, items, N, D, t_feat, t_dot):
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak (MI355X_MICROARCH.md)
 
 
-def exact_all_pairs_shard(args, device):
-    """BASELINE.json configs[4] on one GPU's share: 50k x 8192 exact all-pairs k-NN row-sharded over 8 GPUs = 6250 rows
-    per GPU, every row of the shard a query (morna.py:681-716 per item).  Extra key, never part of `value`: one warm
-    pass, one timed pass; the scan runs on the fp32 matrix cores, so its roof is the fp32 MFMA peak."""
+def exact_all_pairs(args, device, prep, sample_count, shard_of=None, k=20, D=8192):
+    """BASELINE.json configs[4]: exact brute-force k-NN of EVERY item of a 50k x 8192 index against the index
+    (morna.py:681-716 per item), through morna_exact_search_by_item -- the queries are stored rows, widened to fp64 on the
+    device: only the item numbers cross PCIe.  shard_of = (g, G): one GPU's diagonal block of the 8-way row cut instead
+    (its 6250 rows against themselves).  Extra key, never part of `value`: one warm pass, one timed pass; the scan runs on
+    the fp32 matrix cores, so its roof is the fp32 MFMA peak."""
     from morna_amd.annoy import AnnoyIndex
-    from morna_amd.index import prepare_csr
-    from morna_amd.synth import synthetic_intropolis
-    n, D, k = 6250, 8192, 20
-    data = synthetic_intropolis(n, J=args.junctions)
-    prep = prepare_csr(data["keys"], data["row_ptr"], data["samples"], data["cov"], data["sample_count"], 100)
+    from morna_amd.index import ParsedLines
+    lines = ParsedLines.from_arrays(prep, sample_count)
+    if shard_of is not None:
+        lines = lines.shard(*shard_of)
     a = AnnoyIndex(D, device=device)
-    a.stage_junctions(prep["key_bytes"], prep["key_off"], prep["row_ptr"], prep["ids"], prep["cov"], prep["idf"])
-    a.stage_item_order(prep["ext_ids"])
-    a.build_features(prep["n_items"])
+    lines.stage(a)
+    a.build_features(lines.n_items)
     a.unstage_junctions()
-    Qd = a.get_items().astype(np.float64)
-    a.exact_search_batch(Qd, k)
+    n = lines.n_items
+    items = np.arange(n, dtype=np.int32)
+    a.exact_search_by_item_batch(items[:min(n, 4096)], k)        # warm: workspace, code objects
+    a.synchronize()
     a.timer_reset()
     a.timer_enable(True, only=["exact", "exact_scan"])
     t0 = time.perf_counter()
-    ids, d, cnt = a.exact_search_batch(Qd, k)
+    ids, d, cnt = a.exact_search_by_item_batch(items, k)
     wall = time.perf_counter() - t0
     a.timer_enable(False)
     tm = a.timers()
     scan = tm["exact_scan"]
     tfl = scan["bytes"] / 1e12 / (scan["ms"] / 1e3) if scan["ms"] > 0 else 0.0
-    return {"workload": "%d x %d shard of configs[4] (50k x 8192 over 8 GPUs), all %d rows as queries, k=%d" % (n, D, n, k),
+    what = ("rows %d..%d of the %d-sample set (shard %d of %d of configs[4]'s 8-way cut), its %d rows as queries"
+            % (lines.id_offset, lines.id_offset + n, lines.n_items_global, shard_of[0], shard_of[1], n)) if shard_of \
+        else "all %d rows of the %d x %d index as queries (configs[4] at its real size, one GPU)" % (n, n, D)
+    return {"workload": what + ", k=%d, by item" % k, "rows": n, "queries": n,
             "wall_ms": 1e3 * wall, "queries_per_sec": n / wall, "scan_ms": scan["ms"], "exact_group_ms": tm["exact"]["ms"],
-            "self_is_nearest": bool((ids[:, 0] == np.arange(n)).all()),
+            "scan_launches": scan["launches"], "self_is_nearest": bool((ids[:, 0] == items).all() and (cnt == k).all()),
             "roofline": {"kernel": "exact_scan_mfma_kernel", "bound": "mfma", "achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": tfl / MFMA_F32_PEAK_TFLOPS, "flops": scan["bytes"],
-                         "host_copy_note": "wall_ms includes the host <-> device copies of queries and results"}}
+                         "note": "wall_ms = the whole call on the host clock (item numbers in, ids + fp64 distances out); "
+                                 "exact_group_ms = scan + selection + fp64 re-rank by HIP events"}}
+
+
+def query_sweep(args, index, items, k, st):
+    """Latency of the approximate search by batch size (the reference answers ONE query per process, morna.py:1345-1484 ->
+    651-665 / 762-774): nq = 1, 8, 64 and the full batch, by item, each timed over repeated calls on the host clock with the
+    device drained.  For nq = 1 the bytes one query has to move -- its candidates' fp16 rows for the filter, the
+    hyperplanes it meets (every root + one path), the fp32 rows of the survivors are not counted -- against the HBM peak."""
+    out = {}
+    D, dp = args.features, dpad_of(args.features)
+    for nq in (1, 8, 64, len(items)):
+        sub = items[:nq]
+        reps = 30 if nq <= 64 else 10
+        for _ in range(3):
+            index.get_nns_by_item_batch(sub, k, args.search_k)
+        index.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            index.get_nns_by_item_batch(sub, k, args.search_k)
+        index.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / reps
+        index.timer_reset()
+        index.timer_enable(True, only=["query"])
+        index.get_nns_by_item_batch(sub, k, args.search_k)
+        index.timer_enable(False)
+        tq = index.timers()["query"]
+        rows = tq["bytes"] / (4.0 * D) / max(nq, 1)          # hyperplane dots + unique candidates + 1, per query
+        dots = st["n_trees"] + st["max_depth"]
+        cand = max(rows - dots - 1, 0.0)
+        e = {"nq": nq, "ms_per_call": ms, "us_per_query": 1e3 * ms / nq, "kernels_ms": tq["ms"],
+             "rows_touched_per_query": rows,
+             "path": "whole-batch fp16 contraction + traversal" if (nq >= 64 and nq * min(st["leaf_capacity"], rows) >= 2 * st["n_items"])
+                     else "per-candidate fp16 filter (gather)"}
+        if nq == 1:
+            floor_b = cand * dp * 2 + dots * dp * 4
+            e["byte_floor"] = {"bytes": floor_b, "us_at_hbm_peak": floor_b / (HBM_PEAK_GBS * 1e3),
+                               "kernel_us": 1e3 * tq["ms"], "kernel_over_floor": 1e3 * tq["ms"] / max(floor_b / (HBM_PEAK_GBS * 1e3), 1e-9),
+                               "what": "%.0f candidates x %d B (fp16 rows) + %d hyperplanes x %d B" % (cand, dp * 2, dots, dp * 4)}
+        out["nq_%d" % nq] = e
+    return out
 
 
 def sharded_overhead(args, index, n_items, items, k, step):
@@ -186,8 +241,10 @@ def sharded_overhead(args, index, n_items, items, k, step):
             return 1e3 * (time.perf_counter() - t0) / n
         plain = run(lambda: index.get_nns_by_item_batch(items, k, args.search_k))
         shard = run(lambda: ss.get_nns_by_local_items(items, k, args.search_k, n_each=[len(items)]))
+        ss.close()
         return {"plain_query_ms": plain, "sharded_query_ms": shard, "overhead_ms": shard - plain,
-                "path": "query rows all-gathered HBM -> HBM, per-shard top-k packed in HBM, RCCL all_gather_into_tensor, merge kernel"}
+                "path": "inside the library (communicator owned by the handle): query rows ncclAllGather HBM -> HBM, per-shard "
+                        "top-k packed in HBM, ncclAllGather, merge kernel; one host wait"}
     finally:
         dist.destroy_process_group()
         sys.stdout.flush()
@@ -279,25 +336,51 @@ def main():
     if world > 1:
         dist.barrier()
     from morna_amd.annoy import AnnoyIndex
-    from morna_amd.index import prepare_csr
+    from morna_amd.index import ParsedLines, prepare_csr, shard_bounds
     from morna_amd.synth import SEED, query_items, synthetic_intropolis
     from morna_amd.dist import ShardedSearch
 
     N, D, T, Q, k = args.samples, args.features, args.trees, args.queries, args.k
-    data = synthetic_intropolis(N, J=args.junctions, seed=SEED + rank)
+    strong = args.scaling == "strong"
+    data = synthetic_intropolis(N, J=args.junctions, seed=SEED + (0 if strong else rank))
     prep = prepare_csr(data["keys"], data["row_ptr"], data["samples"], data["cov"], data["sample_count"], 100)
-    n_items = prep["n_items"]
+    n_total = prep["n_items"] if strong else None          # (weak: the sum over the ranks' own data sets, below)
     index = AnnoyIndex(D, device=local_rank)
     t_stage = time.perf_counter()   # host -> HBM copy of the junction lines: NOT part of the timed region
-    index.stage_junctions(prep["key_bytes"], prep["key_off"], prep["row_ptr"], prep["ids"], prep["cov"], prep["idf"])
-    index.stage_item_order(prep["ext_ids"])   # the sample ids, in which the lines' lists ascend (as go_index sees them)
+    if strong and world > 1:
+        # ONE data set, cut by rows: this rank's lines carry the GLOBAL idf and first-seen ids (morna.py:357-382) and only
+        # the entries of its own samples (morna_lines_shard); the shards stacked are the single index's matrix, bit for bit
+        part = ParsedLines.from_arrays(prep, data["sample_count"]).shard(rank, world)
+        t_stage = time.perf_counter()
+        part.stage(index)
+        n_items, nnz_local, id_offset = part.n_items, part.nnz, part.id_offset
+        bounds = shard_bounds(n_total, world)
+    else:
+        index.stage_junctions(prep["key_bytes"], prep["key_off"], prep["row_ptr"], prep["ids"], prep["cov"], prep["idf"])
+        index.stage_item_order(prep["ext_ids"])   # the sample ids, in which the lines' lists ascend (as go_index sees them)
+        n_items, nnz_local, id_offset = prep["n_items"], int(len(prep["ids"])), 0
+        bounds = None
     t_stage = time.perf_counter() - t_stage
-    items = query_items(n_items, Q)              # the queries this rank owns (all of them when world == 1)
     sharded = ShardedSearch(index, rank, world, n_items) if (world > 1 or force_sharded) else None
     n_each = None
-    if sharded is not None:
-        n_each = [len(items[g::world]) for g in range(world)]   # every rank knows every rank's share of the queries
-        items = items[rank::world]
+    if strong:
+        # the SAME queries whatever the number of GPUs: Q rows of the whole index; a rank hands over those it owns
+        all_items = query_items(n_total, Q)
+        if bounds is not None:
+            owner = np.searchsorted(np.asarray(bounds), all_items, side="right") - 1
+            n_each = [int((owner == g).sum()) for g in range(world)]
+            items = (all_items[owner == rank] - bounds[rank]).astype(np.int32)
+            answer_order = np.concatenate([np.nonzero(owner == g)[0] for g in range(world)])   # answers come rank 0's first
+        else:
+            items, answer_order = all_items, np.arange(len(all_items))
+            n_each = [len(items)] if sharded is not None else None
+    else:
+        items = query_items(n_items, Q)              # the queries this rank owns (all of them when world == 1)
+        answer_order = None
+        if sharded is not None:
+            n_each = [len(items[g::world]) for g in range(world)]   # every rank knows every rank's share of the queries
+            items = items[rank::world]
+        n_total = n_items * world
 
     def step(split=False):
         """One pass of the hot path.  split: wait for the build before the queries start, so that the two halves can be
@@ -367,15 +450,37 @@ def main():
     index.timer_enable(False)
     timers = index.timers()
 
+    verify = None
+    if args.verify and strong:
+        # every rank takes part (the sharded exact search is a collective): exact answers to 64 of the queries, in the
+        # queries' own order whatever the number of shards, as a digest; recall of the approximate answers against them
+        import hashlib
+        nv = min(64, len(answer_order))
+        if sharded is not None and world > 1:
+            eids, ed, _ = sharded.exact_search_by_local_items(items, k, n_each=n_each)
+            back = np.argsort(answer_order)                  # answer position of query j
+            eids, ed, aids = eids[back][:nv], ed[back][:nv], np.asarray(res[0])[back][:nv]
+        else:
+            eids, ed, _ = index.exact_search_by_item_batch(items[:nv], k)
+            aids = np.asarray(res[0])[:nv]
+            eids = eids.astype(np.int64)
+        rec = float(np.mean([len(set(aids[i].tolist()) & set(eids[i].tolist())) / float(k) for i in range(nv)]))
+        verify = {"queries": nv, "exact_digest": hashlib.sha256(np.ascontiguousarray(eids, np.int64).tobytes()
+                                                               + np.ascontiguousarray(ed, np.float64).tobytes()).hexdigest(),
+                  "recall_at_k_vs_exact": rec}
     out = None
     if rank == 0:
         # One roofline entry per kernel group, from the HIP-event timers of the library (events recorded on the
         # stream the kernels run on) and the algorithmic bytes of SURVEY.md 8(d) that the library counts per launch.
         # The split group is priced at one pass over the rows per level (see below), not per (row, split node).
-        kernels_of = {"features": ("morna::accumulate", "morna::transpose_convert_kernel", "morna::hash_keys_kernel",
-                                   "morna::col_", "morna::line_", "morna::row_norms_kernel"),
-                      "two_means": ("morna::two_means",), "split": ("morna::split_", "morna::rows_to_half", "morna::invert_kernel"),
-                      "partition": ("morna::partition_kernel",), "query": ("morna::query_",)}
+        # kernel-name prefixes of each group as the library launches them today (features.hip, forest.hip, splitmm.hip,
+        # knn.hip): the HBM-side bytes of profiles/*_traffic.json are summed over these
+        kernels_of = {"features": ("morna::accumulate", "morna::transpose_norms_kernel", "morna::hash_keys_kernel", "morna::col_",
+                                   "morna::line_", "morna::row_norms_kernel", "morna::flags_to_serial_kernel"),
+                      "two_means": ("morna::two_means",), "tm_strip": ("morna::two_means_strip_kernel",),
+                      "tm_wave": ("morna::two_means_wave_kernel",),
+                      "split": ("morna::split_", "morna::rows_to_half", "morna::invert_kernel", "morna::order_", "morna::sched_"),
+                      "partition": ("morna::partition_kernel", "morna::post_counts_kernel"), "query": ("morna::query_",)}
         tj = None
         import glob
         for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3_traffic.json")), reverse=True):
@@ -409,11 +514,18 @@ def main():
                     + 4.0 * dpad_of(D) * st["n_split"] * n_steps
                 gbs = min_bytes / 1e9 / (tm["ms"] / 1e3)
                 flops = 2.0 * D * (st["split_rows"] + st["n_split"]) * n_steps      # one dot per row and split node
-                executed = 2.0 * n_items * st["n_split"] * D * n_steps             # every row x every hyperplane of its level
+                mm = tms.get("split_mm", {"ms": 0, "bytes": 0, "launches": 0})
                 g.update(achieved=gbs, frac=gbs / HBM_PEAK_GBS, alg_bytes_per_launch=int(min_bytes / levels),
                          alg_bytes_per_launch_no_reuse=tm["bytes"] // launches,
-                         mfma_floor={"algorithmic_tflops": flops / 1e12 / (tm["ms"] / 1e3), "peak": MFMA_F16_PEAK_TFLOPS,
-                                     "executed_tflops": executed / 1e12 / (tm["ms"] / 1e3)})
+                         mfma_floor={"algorithmic_tflops": flops / 1e12 / (tm["ms"] / 1e3), "peak": MFMA_F16_PEAK_TFLOPS})
+                if mm["ms"] > 0:
+                    # the contraction alone: flops of the (row tile, task chunk) products it LAUNCHED -- counted by the
+                    # library, through the per-tile task lists on the device -- over ITS event time
+                    g["mfma_floor"].update(contraction_ms_per_step=mm["ms"] / max(n_steps, 1),
+                                           executed_flops_per_step=mm["bytes"] / max(n_steps, 1),
+                                           executed_tflops=mm["bytes"] / 1e12 / (mm["ms"] / 1e3),
+                                           executed_frac_of_peak=mm["bytes"] / 1e12 / (mm["ms"] / 1e3) / MFMA_F16_PEAK_TFLOPS,
+                                           executed_over_needed=mm["bytes"] / max(flops, 1.0))
             if name == "query":
                 # SURVEY.md 8(d) prices a query at 4*D bytes per hyperplane dot and per candidate row (27 GB per 1000
                 # queries here).  The candidate filter no longer gathers candidate rows: one contraction of all
@@ -444,7 +556,7 @@ def main():
             if g["frac"] > 1.0:
                 raise SystemExit("bench.py: roofline fraction %.2f > 1 for %s -- the bytes or the peak are wrong" % (g["frac"], name))
             return g
-        groups = {n: group(n, timers, n_bd) for n in GROUPS}
+        groups = {n: group(n, timers, n_bd) for n in GROUPS + ("tm_strip", "tm_wave")}   # the two two_means kernels beside their group
         groups = {n: g for n, g in groups.items() if g}
         notes = {"two_means": "one chain of 200 dependent steps per split node (annoy's two_means): bound by the latency of "
                               "that chain at shallow levels and by the random-row gather from HBM at deep ones",
@@ -452,26 +564,38 @@ def main():
                           "bytes = one pass over the fp32 rows per level + hyperplanes + side bytes (rows reused across trees on chip)",
                  "features": "fp64 accumulation in file order in LDS tiles; the nnz stream is read once per sample tile",
                  "query": "traversal || whole-batch fp16 filter contraction on the matrix cores, then fp32 dots for the survivors"}
+        notes["tm_strip"] = "two_means at levels of <= 2 nodes per CU: four waves per node, a 200-step latency chain"
+        notes["tm_wave"] = "two_means at the deep levels: one wave per node, bound by the gather of random 12-KB rows from HBM"
+        for n, g in groups.items():
+            g["note"] = notes[n]
         roofline = dict(group(dominant, timed, args.steps), note=notes[dominant], measured="HIP events in the timed region")
-        total_samples = n_items * world * args.steps
+        total_samples = n_total * args.steps
+        which = "configs[3]" if (strong and N == 200_000 and world == 8) else "configs[2]" if N == 50_000 else "a size of its own"
+        if strong:
+            workload = ("synthetic intropolis %d samples x %d features%s, %d trees, %d by-item queries, k=%d, search_k=%d "
+                        "(BASELINE.json %s)" % (N, D, " as ONE data set cut into %d row shards" % world if world > 1 else "",
+                                                T, Q, k, args.search_k, which))
+        else:
+            workload = ("synthetic intropolis %d samples/GPU x %d features, %d trees, %d by-item queries, k=%d, search_k=%d "
+                        "(weak scaling of BASELINE.json configs[2]: a data set per GPU)" % (N, D, T, Q, k, args.search_k))
         out = {
             "metric": "samples indexed/sec (index build + %d queries, k=%d) at %dk x %d" % (Q, k, N // 1000, D),
             "value": total_samples / elapsed,
             "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "synthetic intropolis %d samples/GPU x %d features, %d trees, %d by-item queries, "
-                                   "k=%d, search_k=%d (BASELINE.json configs[2])" % (N, D, T, Q, k, args.search_k),
-                       "samples_per_gpu": n_items, "features": D, "n_trees": T, "queries": Q, "k": k,
-                       "search_k": args.search_k, "nnz_per_gpu": int(len(prep["ids"])), "junction_lines": int(len(prep["idf"])),
-                       "parallelism": "rows sharded over %d GPU(s), RCCL all-gather of per-shard top-k" % world},
-            "index_samples_per_sec": n_items * world * args.steps / tb,
+            "config": {"workload": workload,
+                       "samples_total": n_total, "samples_per_gpu": n_items, "features": D, "n_trees": T, "queries": Q, "k": k,
+                       "search_k": args.search_k, "nnz_per_gpu": nnz_local, "junction_lines": int(len(prep["idf"])),
+                       "parallelism": "rows sharded over %d GPU(s)%s, RCCL all-gather of per-shard top-k inside the library"
+                                      % (world, " (one data set, global idf and ids)" if strong else " (a data set per GPU)")},
+            "index_samples_per_sec": n_total * args.steps / tb,
             "queries_per_sec": Q * args.steps / tq,
             # if the junction lines had to cross PCIe on every step (pageable host buffers, measured once)
             "stage_ms": 1e3 * t_stage,
-            "samples_per_sec_pcie_inclusive": n_items * world / (elapsed / args.steps + t_stage),
+            "samples_per_sec_pcie_inclusive": n_total / (elapsed / args.steps + t_stage),
             # build / query halves: from the breakdown pass (the build drained before the queries start), not the timed region
             "build_ms_per_step": 1e3 * tb / args.steps, "query_ms_per_step": 1e3 * tq / args.steps,
             # breakdown: %d extra steps AFTER the timed region, every group bracketed with events
@@ -482,13 +606,13 @@ def main():
             "roofline": roofline,
             "rooflines": groups,
         }
-        if args.verify:
-            ids = res[0]
-            eids, _, _ = index.exact_search_batch(index.get_items()[items[:64]].astype(np.float64), k)
-            rec = np.mean([len(set(ids[i].tolist()) & set(eids[i].tolist())) / float(k) for i in range(len(eids))])
-            out["recall_at_k_vs_exact"] = float(rec)
+        if verify is not None:
+            out["verify"] = verify
         if world == 1 and not args.no_extras:
-            out["exact_all_pairs_shard"] = exact_all_pairs_shard(args, local_rank)
+            out["query_sweep"] = query_sweep(args, index, items, k, st)
+            if strong and N == 50_000:
+                out["exact_all_pairs"] = exact_all_pairs(args, local_rank, prep, data["sample_count"])
+                out["exact_all_pairs_shard"] = exact_all_pairs(args, local_rank, prep, data["sample_count"], shard_of=(0, 8))
             if sharded is None:
                 out["sharded_path_at_world_1"] = sharded_overhead(args, index, n_items, items, k, step)
         if world == 1 and not args.no_cpu_baseline:
@@ -500,6 +624,8 @@ def main():
         print(json.dumps(out))
     if dist.is_initialized():
         dist.barrier()
+        if sharded is not None:
+            sharded.close()
         dist.destroy_process_group()
 
 

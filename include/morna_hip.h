@@ -294,7 +294,10 @@ enum {
     MORNA_T_EXACT = 5,      /* exact scan + re-rank                            */
     MORNA_T_QUERY_FILTER = 6, /* part of MORNA_T_QUERY: the whole-batch fp16 contraction (bytes = its flops) */
     MORNA_T_EXACT_SCAN = 7, /* part of MORNA_T_EXACT: the fp32 scan (bytes = its flops when it ran on the matrix cores) */
-    MORNA_T_COUNT = 8
+    MORNA_T_SPLIT_MM = 8,   /* part of MORNA_T_SPLIT: the fp16 contraction alone (bytes = the flops of the tiles it LAUNCHED) */
+    MORNA_T_TM_STRIP = 9,   /* part of MORNA_T_TWO_MEANS: levels run by two_means_strip_kernel (four waves per node) */
+    MORNA_T_TM_WAVE = 10,   /* part of MORNA_T_TWO_MEANS: levels run by two_means_wave_kernel (one wave per node) */
+    MORNA_T_COUNT = 11
 };
 /* HIP-event timing of the kernels on the handle's own stream.  on: 0 off, 1 every group, otherwise a mask with bit
  * (MORNA_T_x + 1) set for each group to time (each event pair costs the stream a few microseconds of idle) */

@@ -38,7 +38,7 @@ void resolve_timers(morna_index *h)
     if (h->pending_ev.empty()) return;
     (void)hipStreamSynchronize(h->stream);
     unsigned long long rows = 0;
-    bool have_q = false;
+    bool have_q = false, have_mm = false;
     for (const PendingEv &pe : h->pending_ev) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
@@ -47,6 +47,7 @@ void resolve_timers(morna_index *h)
             h->timers[pe.which].bytes += pe.bytes;
         }
         if (pe.which == MORNA_T_QUERY) have_q = true;
+        if (pe.which == MORNA_T_SPLIT_MM) have_mm = true;
         h->free_ev.push_back(pe.a);
         h->free_ev.push_back(pe.b);
     }
@@ -56,6 +57,14 @@ void resolve_timers(morna_index *h)
         if (hipMemcpy(&rows, h->d_stat.p, sizeof(rows), hipMemcpyDeviceToHost) == hipSuccess) {
             h->timers[MORNA_T_QUERY].bytes += (int64_t)rows * 4 * h->dim;
             (void)hipMemset(h->d_stat.p, 0, sizeof(rows));
+        }
+    }
+    if (have_mm && h->d_stat.p) {
+        // 256 x 256 x dpad products the split contraction launched through its per-tile task lists (splitmm.hip)
+        unsigned long long tiles = 0;
+        if (hipMemcpy(&tiles, h->d_stat.p + 1, sizeof(tiles), hipMemcpyDeviceToHost) == hipSuccess) {
+            h->timers[MORNA_T_SPLIT_MM].bytes += (int64_t)tiles * 2 * 256 * 256 * h->dpad;
+            (void)hipMemset(h->d_stat.p + 1, 0, sizeof(tiles));
         }
     }
 }
@@ -770,7 +779,7 @@ int morna_timer_reset(morna_index *h)
     HIP_TRY(hipSetDevice(h->device));
     resolve_timers(h);
     for (int i = 0; i < MORNA_T_COUNT; i++) h->timers[i] = Timer();
-    if (h->d_stat.p) HIP_TRY(hipMemset(h->d_stat.p, 0, sizeof(unsigned long long)));
+    if (h->d_stat.p) HIP_TRY(hipMemset(h->d_stat.p, 0, 2 * sizeof(unsigned long long)));
     return MORNA_OK;
 }
 

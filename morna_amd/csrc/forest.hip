@@ -1341,6 +1341,8 @@ int build_forest(morna_index *h, int32_t n_trees, uint32_t seed)
                 // and four waves per node only add work there.  MORNA_TM_STRIP=0: one wave per node everywhere.
                 static const bool tm_strip_on = !(getenv("MORNA_TM_STRIP") && atoi(getenv("MORNA_TM_STRIP")) == 0);
                 const bool tm_strip = tm_strip_on && A <= 2 * h->n_cus;
+                const bool strip_runs = tm_strip && (nvq == 12 || nvq == 8 || nvq == 4 || (nvq >= 16 && nvq <= 32 && nvq % 4 == 0));
+                ScopedTimer tk(h, strip_runs ? MORNA_T_TM_STRIP : MORNA_T_TM_WAVE, 4 * (int64_t)D * (TM_ITERS + 2) * A);   // per kernel, beside the group
 #define TMS_LAUNCH(NVV)                                                                                                 \
     hipLaunchKernelGGL((two_means_strip_kernel<NVV, TM_STRIP_DEPTH>), dim3((unsigned)A), dim3(256), 0, h->stream, h->X.p, \
                        h->rowinfo.p, N, dpad, work.p, d_tasks.p, seed, hp_level, d_ones.p)

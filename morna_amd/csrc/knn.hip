@@ -1324,7 +1324,7 @@ int exact_search_any(morna_index *h, const double *q_host, const float *q_dev, c
         HIP_TRY(hipGetLastError());
         const float eps = exact_scan_eps(dpad, nb >= 32);   // which scan ran
         ScopedTimer tm_sel(h, MORNA_T_EXACT, 0);            // selection + fp64 re-rank: the same group as the scan
-        static const bool select2_on = !(getenv("MORNA_EXACT_SELECT2") && atoi(getenv("MORNA_EXACT_SELECT2")) == 0);
+        const bool select2_on = !(getenv("MORNA_EXACT_SELECT2") && atoi(getenv("MORNA_EXACT_SELECT2")) == 0);   // (read per call: a test switches it)
         for (;;) {
             MORNA_TRY(h->ex_cand.alloc((size_t)batch * cap));
             MORNA_TRY(h->ex_cdist.alloc((size_t)batch * cap));

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void split_active_list_kernel(const uint8_t *_
 
 // col_first[tile] = chunks of `cols` tasks in the lists of the tiles before it (one workgroup; n_rt is a few hundred)
 __global__ __launch_bounds__(1024) void split_active_scan_kernel(const int32_t *__restrict__ col_count, int32_t n_rt, int32_t cols,
-                                                                 int32_t *__restrict__ col_first)
+                                                                 int32_t *__restrict__ col_first, unsigned long long *__restrict__ launched)
 {
     __shared__ int s_part[1024];
     const int per = (n_rt + 1023) / 1024, b = threadIdx.x * per;
@@ -367,7 +367,10 @@ __global__ __launch_bounds__(1024) void split_active_scan_kernel(const int32_t *
         col_first[i] = run;
         run += (col_count[i] + cols - 1) / cols;
     }
-    if (threadIdx.x == 1023) col_first[n_rt] = s_part[1023];
+    if (threadIdx.x == 1023) {
+        col_first[n_rt] = s_part[1023];
+        if (launched) atomicAdd(launched, (unsigned long long)s_part[1023]);   // (tile, chunk) pairs the contraction will execute
+    }
 }
 
 // ---- the pairs the filter left open: canonical fp32 dot, one wave per pair ------------------------
@@ -613,10 +616,15 @@ int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, in
                                lists.p + (size_t)n_rt * n_tasks);
             col_list = lists.p;
             col_count = lists.p + (size_t)n_rt * n_tasks;
+            // d_stat[1]: 256 x 256 tiles launched through the lists while the MORNA_T_SPLIT_MM timer is on (resolve_timers prices them)
+            const bool count_tiles = h->timing && (h->timing_mask & (1u << MORNA_T_SPLIT_MM));
             hipLaunchKernelGGL(split_active_scan_kernel, dim3(1), dim3(1024), 0, h->stream, col_count, (int32_t)n_rt, 256,
-                               lists.p + (size_t)n_rt * n_tasks + n_rt);
+                               lists.p + (size_t)n_rt * n_tasks + n_rt, count_tiles ? h->d_stat.p + 1 : (unsigned long long *)nullptr);
             col_first = col_count + n_rt;
         }
+        // executed flops: every launched (row tile, chunk of 256 tasks) pair is a 256 x 256 x dpad product; through the lists
+        // their number is only known on the device (counted above)
+        ScopedTimer tmm(h, MORNA_T_SPLIT_MM, lists_on ? 0 : 2ll * 256 * 256 * h->dpad * (int64_t)n_rt * n_ct);
         const float eps1 = (4.f * (float)h->dpad + 2.f) * 5.9604645e-8f + 4.1e-6f;   // EACC for ONE chain of dpad products
         HIP_TRY(hipFuncSetAttribute((const void *)split_mm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 256 * 4));
         hipLaunchKernelGGL(split_mm_kernel<true>, dim3(8u * ((n_rt + 7) / 8) * n_ct), dim3(1024), 128 * 256 * 4, h->stream, rows16, rows_n,
@@ -626,6 +634,7 @@ int split_mm_level(morna_index *h, const SplitTask *d_tasks, int32_t n_tasks, in
         const unsigned n_rt = (unsigned)((N + 127) / 128), n_ct = (unsigned)((n_tasks + 127) / 128);
         static_assert(MM16_LDS == 128 * 128 * 4, "the slabs and the result tile share the dynamic LDS");
         HIP_TRY(hipFuncSetAttribute((const void *)split_mm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 4));
+        ScopedTimer tmm(h, MORNA_T_SPLIT_MM, 2ll * 128 * 128 * h->dpad * (int64_t)n_rt * n_ct);
         hipLaunchKernelGGL(split_mm_kernel<false>, dim3(8u * ((n_rt + 7) / 8) * n_ct), dim3(512), 128 * 128 * 4, h->stream, rows16, rows_n,
                            rows_e, N, h->dpad, h16.p, hn.p, hn.p + n_slots, n_tasks, d_tasks, inv, item_at, sm_eps(h->dpad), side,
                            ones, amb_count, amb, (unsigned int)cap, (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr);

@@ -395,6 +395,13 @@ def test_c5_exact_all_pairs_full_size_by_item_one_gpu(c5, capi):
     assert ids2.tolist() == ids[:16].tolist() and d2.tobytes() == d[:16].tobytes()
     ids3, d3, _ = a.exact_search_batch(X[sub].astype(np.float64), k)         # the same queries handed over as fp64 vectors
     assert ids3.tolist() == ids[:600].tolist() and d3.tobytes() == d[:600].tobytes()
+    # the two-pass selection (shards of more than 8192 rows) against the k-round one it replaces
+    os.environ["MORNA_EXACT_SELECT2"] = "0"
+    try:
+        ids4, d4, _ = a.exact_search_by_item_batch(sub, k)
+    finally:
+        del os.environ["MORNA_EXACT_SELECT2"]
+    assert ids4.tolist() == ids[:600].tolist() and d4.tobytes() == d[:600].tobytes()
     c5["all_pairs"] = (ids, d)
 
 
