@@ -11,9 +11,10 @@ LIB_PATH = os.environ.get("MORNA_LIB") or os.path.join(os.path.dirname(os.path.a
 
 OK, E_INVALID, E_HIP, E_STATE, E_RANGE, E_IO, E_EMPTY = 0, -1, -2, -3, -4, -5, -6
 
-T_FEATURES, T_TWO_MEANS, T_SPLIT, T_PARTITION, T_QUERY, T_EXACT, T_QUERY_FILTER, T_EXACT_SCAN = range(8)
+T_FEATURES, T_TWO_MEANS, T_SPLIT, T_PARTITION, T_QUERY, T_EXACT, T_QUERY_FILTER, T_EXACT_SCAN, T_SPLIT_MM, T_TM_STRIP, T_TM_WAVE = range(11)
 COMM_ID_BYTES = 128
-TIMER_NAMES = ["features", "two_means", "split", "partition", "query", "exact", "query_filter", "exact_scan"]
+TIMER_NAMES = ["features", "two_means", "split", "partition", "query", "exact", "query_filter", "exact_scan", "split_mm",
+               "tm_strip", "tm_wave"]
 
 
 class ForestStats(C.Structure):

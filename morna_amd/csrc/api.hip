@@ -632,7 +632,11 @@ static bool forest_tables_ok(const FileHeader &hd, const std::vector<int32_t> &p
         if (tree[(size_t)i] < 0 || tree[(size_t)i] >= T) return false;
         if (start < 0 || count < 0 || (int64_t)start + count > N) return false;
         if (i < T && (tree[(size_t)i] != i || start != 0 || count != N)) return false;   // roots are nodes 0 .. T-1
-        if (c0 < 0 || c1 < 0) {
+        // a node splits exactly when it holds more than a leaf may (annoy's _make_tree; the traversal kernel reads the
+        // children and the hyperplane of every root with n_items > K without looking at the record first)
+        const bool splits = c0 >= 0 && c1 >= 0;
+        if (splits != ((int64_t)count > (int64_t)hd.dim + 2)) return false;
+        if (!splits) {
             if (c0 != -1 || c1 != -1 || hp[(size_t)i] != -1) return false;
             continue;
         }
@@ -640,12 +644,22 @@ static bool forest_tables_ok(const FileHeader &hd, const std::vector<int32_t> &p
         if (c0 <= i || c1 <= i || c0 >= n || c1 >= n || c0 == c1) return false;
         if (refs[(size_t)c0]++ || refs[(size_t)c1]++) return false;
         if (tree[(size_t)c0] != tree[(size_t)i] || tree[(size_t)c1] != tree[(size_t)i]) return false;
+        // the children partition the parent's segment of the tree's permutation, left child first, neither empty
+        const int32_t s0 = rec[(size_t)c0 * 4 + 2], n0 = rec[(size_t)c0 * 4 + 3], s1 = rec[(size_t)c1 * 4 + 2], n1 = rec[(size_t)c1 * 4 + 3];
+        if (s0 != start || n0 <= 0 || n1 <= 0 || (int64_t)n0 + n1 != count || s1 != start + n0) return false;
         if (hp[(size_t)i] < 0 || hp[(size_t)i] >= hd.n_split || slot_used[(size_t)hp[(size_t)i]]++) return false;
     }
     for (int64_t i = 0; i < n; i++)
         if ((i < T) != (refs[(size_t)i] == 0)) return false;
     for (int32_t v : perm)
         if (v < 0 || v >= N) return false;
+    // every tree's permutation lists every item once (a leaf's segment is handed to the refine kernel as candidate ids)
+    std::vector<uint8_t> seen((size_t)std::max<int64_t>(N, 1));
+    for (int64_t t = 0; t < T; t++) {
+        std::fill(seen.begin(), seen.end(), 0);
+        for (int64_t i = 0; i < N; i++)
+            if (seen[(size_t)perm[(size_t)(t * N + i)]]++) return false;
+    }
     return true;
 }
 

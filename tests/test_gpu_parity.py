@@ -477,6 +477,21 @@ def test_load_rejects_damaged_files(tmp_path):
     bad = bytearray(blob)
     bad[hp0:hp0 + 4] = struct.pack("<i", st["n_split"])   # hyperplane slot out of range
     attempt(bytes(bad))
+    # what the traversal kernel relies on without looking -- a node has children exactly when it holds more
+    # than K = dim + 2 items, and the children cut the parent's segment in two
+    nodes = a.get_forest()["node_rec"]                    # [n_nodes][6] = kind, tree, start, count, child0, child1
+    leaf = int(np.nonzero(nodes[:, 0] == 1)[0][0])
+    bad = bytearray(blob)
+    bad[rec0 + 16 * leaf + 12:rec0 + 16 * leaf + 16] = struct.pack("<i", 12 + 3)   # a leaf that claims K + 1 items
+    attempt(bytes(bad))
+    split = int(np.nonzero(nodes[:, 0] == 0)[0][-1])
+    c1 = int(nodes[split, 5])
+    bad = bytearray(blob)
+    bad[rec0 + 16 * c1 + 8:rec0 + 16 * c1 + 16] = struct.pack("<ii", int(nodes[c1, 2]) + 1, int(nodes[c1, 3]) - 1)   # a gap between the children
+    attempt(bytes(bad))
+    bad = bytearray(blob)
+    bad[rows_end + 4:rows_end + 8] = bad[rows_end:rows_end + 4]       # an item twice in a tree's permutation
+    attempt(bytes(bad))
     b = AnnoyIndex(12)
     b.load(path)                                          # and the intact file still loads
     assert b.get_nns_by_item(5, 4, -1) == a.get_nns_by_item(5, 4, -1)

@@ -117,7 +117,7 @@ def test_many_items_tiny_rows_deep_trees():
 
 
 def test_feature_build_linearity_and_order_invariance():
-    """50k-sample synthetic intropolis slice at D = 3000."""
+    """A 20 000-sample, 6 000-line synthetic intropolis at D = 3000: size-independent properties of the feature build."""
     from morna_amd.annoy import AnnoyIndex
     from morna_amd.index import prepare_csr
     from morna_amd.synth import synthetic_intropolis
