@@ -228,6 +228,191 @@ __global__ __launch_bounds__(Q_THREADS) void query_traverse_kernel(QueryParams P
     }
 }
 
+// ---- small batches: ONE query spread over the chip ----------------------------------------------------------------
+// The reference answers one query per process (morna.py:1345-1484 -> 651-665 / 762-774).  With one workgroup per query
+// (above) a lone query has one CU of 256: its ~200 root margins and the ~2000 candidate rows of its leaf are read by four
+// waves, 0.78 ms at C3 against 2 us for the bytes at the HBM rate.  For batches too small to fill the chip the same
+// arithmetic is dealt out: (A) a wave per (query, tree) for the root margins, (B) one wave per query for the best-first
+// descent -- a chain of dependent pops, each a node record, a hyperplane and one canonical dot --, (C) a wave per two
+// candidates for the CANONICAL fp32 dot of every candidate (no fp16 filter: twice the bytes of the filter, but one
+// dependent stage less: no k-th smallest bound, no compaction, no second gather), (D) the k smallest (distance, id) of
+// the keys by one workgroup.  Same operations on the same values as the batch forms: identical answers.
+__global__ __launch_bounds__(Q_THREADS) void query_roots_kernel(QueryParams P)
+{
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int64_t qi = blockIdx.y;
+    const int nvec = P.dpad / 4;
+    const float4 *q = P.items ? (const float4 *)(P.X + (int64_t)P.items[qi] * P.dpad) : (const float4 *)(P.Q + qi * P.dpad);
+    if (blockIdx.x == 0 && w == Q_WAVES - 1) {
+        const float pp = wave_dot(q, q, nvec, lane);
+        if (lane == 0) P.qpp[qi] = pp;
+    }
+    const int t = blockIdx.x * Q_WAVES + w;
+    if (t >= P.n_trees || !(P.n_items > P.K)) return;   // (roots that are leaves: the descent seeds the queue itself)
+    uint64_t *pq = P.pq + qi * P.n_nodes;
+    const float m = wave_dot((const float4 *)(P.hp + (int64_t)P.node_hp[t] * P.dpad), q, nvec, lane);
+    if (lane == 0) {
+        pq[2 * t] = pq_key(m, P.node_rec[4 * t + 1]);       // min(+inf, margin), children[1]
+        pq[2 * t + 1] = pq_key(-m, P.node_rec[4 * t + 0]);  // min(+inf, -margin), children[0]
+    }
+}
+
+#define PQ_LDS 1024   // queue entries kept in LDS by the one-wave descent; entries beyond stay in the global array
+template <bool BM_LDS>
+__global__ __launch_bounds__(WAVE) void query_descend_kernel(QueryParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint64_t s_pq[PQ_LDS];
+    __shared__ int s_ncand;
+    const int lane = threadIdx.x;
+    const int64_t qi = blockIdx.x;
+    const int nvec = P.dpad / 4;
+    const int T = P.n_trees;
+    uint32_t *bm = BM_LDS ? (uint32_t *)smem : P.bm_global + (size_t)qi * P.bm_words;
+    const float4 *q = P.items ? (const float4 *)(P.X + (int64_t)P.items[qi] * P.dpad) : (const float4 *)(P.Q + qi * P.dpad);
+    uint64_t *gpq = P.pq + qi * P.n_nodes;
+    int32_t *cand = P.cand + qi * P.cap;
+    const bool roots_split = P.n_items > P.K;
+    int hn = roots_split ? 2 * T : T;
+    for (int i = lane; i < P.bm_words; i += WAVE) bm[i] = 0u;
+    for (int i = lane; i < hn && i < PQ_LDS; i += WAVE) s_pq[i] = roots_split ? gpq[i] : pq_key(INFINITY, i);
+    if (!roots_split)
+        for (int i = PQ_LDS + lane; i < hn; i += WAVE) gpq[i] = pq_key(INFINITY, i);
+    if (lane == 0) s_ncand = 0;
+    __syncthreads();   // (one wave: orders the LDS / global initialisation in front of the loop)
+    int ndots = roots_split ? T : 0;
+    int64_t nn = 0;
+    const int64_t search_k = P.search_k;
+    while (nn < search_k) {
+        uint64_t best = 0;
+        int bestpos = -1;
+        for (int i = lane; i < hn; i += WAVE) {
+            const uint64_t kk = i < PQ_LDS ? s_pq[i] : gpq[i];
+            if (kk > best) { best = kk; bestpos = i; }
+        }
+        const uint64_t top = wave_max_u64(best);
+        if (top == 0) break;                       // queue empty
+        if (best == top && bestpos >= 0) {         // exactly one lane owns it
+            if (bestpos < PQ_LDS) s_pq[bestpos] = 0;
+            else gpq[bestpos] = 0;
+        }
+        const int32_t node = (int32_t)(uint32_t)top;
+        const float d = f32_from_orderable((uint32_t)(top >> 32));
+        const int4 rec = *(const int4 *)(P.node_rec + 4 * (int64_t)node);   // child0, child1, start, count
+        if (rec.x < 0) {
+            const int32_t *src_ids = P.perm + (int64_t)P.node_tree[node] * P.n_items + rec.z;
+            for (int i = lane; i < rec.w; i += WAVE) {
+                const int32_t id = src_ids[i];
+                const uint32_t bit = 1u << (id & 31);
+                const uint32_t old = atomicOr(&bm[id >> 5], bit);
+                if (!(old & bit)) {
+                    const int slot = atomicAdd(&s_ncand, 1);
+                    if (slot < P.cap) cand[slot] = id;
+                }
+            }
+            nn += rec.w;
+        } else {
+            const float m = wave_dot((const float4 *)(P.hp + (int64_t)P.node_hp[node] * P.dpad), q, nvec, lane);
+            if (lane == 0) {
+                const uint64_t k1 = pq_key(d < m ? d : m, rec.y), k0 = pq_key(d < -m ? d : -m, rec.x);
+                if (hn < PQ_LDS) s_pq[hn] = k1; else gpq[hn] = k1;
+                if (hn + 1 < PQ_LDS) s_pq[hn + 1] = k0; else gpq[hn + 1] = k0;
+            }
+            hn += 2;
+            ndots++;
+        }
+        __syncthreads();   // one wave: the queue writes above are seen by the next scan
+    }
+    if (lane == 0) {
+        const int nc = s_ncand;
+        P.ncand[qi] = nc;
+        atomicAdd(P.stat, (unsigned long long)(ndots + (nc < P.cap ? nc : P.cap) + 1));
+    }
+}
+
+#define QS_CPW 2   // candidates per wave of query_cand_dots_kernel
+__global__ __launch_bounds__(Q_THREADS) void query_cand_dots_kernel(QueryParams P)
+{
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int64_t qi = blockIdx.y;
+    const int nvec = P.dpad / 4;
+    const int ncand = P.ncand[qi] < P.cap ? P.ncand[qi] : P.cap;
+    const int c0 = (blockIdx.x * Q_WAVES + w) * QS_CPW;
+    if (c0 >= ncand) return;
+    const float4 *q = P.items ? (const float4 *)(P.X + (int64_t)P.items[qi] * P.dpad) : (const float4 *)(P.Q + qi * P.dpad);
+    const int32_t *cand = P.cand + qi * P.cap;
+    uint64_t *keys = P.keys + qi * P.cap;
+    const float pp = P.qpp[qi];
+#pragma unroll
+    for (int j = 0; j < QS_CPW; j++) {
+        const int c = c0 + j;
+        if (c < ncand) {
+            const int32_t id = cand[c];
+            const float pqv = wave_dot((const float4 *)(P.X + (int64_t)id * P.dpad), q, nvec, lane);
+            if (lane == 0) keys[c] = ((uint64_t)f32_orderable(ang_dist(pp, P.norm2[id], pqv)) << 32) | (uint32_t)id;
+        }
+    }
+}
+
+// the k smallest (distance, id) keys of a query's candidates, in order: every wave extracts the k smallest of its share in
+// registers (no barrier), the waves' lists are merged by counting
+#define QT_HELD 16
+__global__ __launch_bounds__(Q_THREADS) void query_topk_kernel(QueryParams P)
+{
+    __shared__ uint64_t s_red[Q_WAVES];
+    __shared__ uint64_t s_top[Q_WAVES * KTH_MAX_K];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int64_t qi = blockIdx.x;
+    const uint64_t *keys = P.keys + qi * P.cap;
+    const int nsel = P.ncand[qi] < P.cap ? P.ncand[qi] : P.cap;
+    const int kout = P.k < nsel ? P.k : nsel;
+    auto emit = [&](int r, uint64_t key) {
+        P.ids_out[qi * P.k + r] = (int32_t)(uint32_t)key;
+        const float d = f32_from_orderable((uint32_t)(key >> 32));
+        P.dist_out[qi * P.k + r] = sqrtf(d > 0.f ? d : 0.f);   // normalized_distance
+    };
+    if (nsel <= Q_THREADS * QT_HELD && P.k <= KTH_MAX_K) {
+        uint64_t held[QT_HELD];
+#pragma unroll
+        for (int u = 0; u < QT_HELD; u++) held[u] = tid + Q_THREADS * u < nsel ? keys[tid + Q_THREADS * u] : ~0ull;
+        uint64_t prev = 0;
+        for (int r = 0; r < kout; r++) {
+            uint64_t best = ~0ull;
+#pragma unroll
+            for (int u = 0; u < QT_HELD; u++)
+                if ((r == 0 || held[u] > prev) && held[u] < best) best = held[u];
+            prev = wave_min_u64(best);
+            if (lane == 0) s_top[w * KTH_MAX_K + r] = prev;   // ~0: this wave has run out of keys
+        }
+        __syncthreads();
+        // Q_WAVES sorted lists of kout keys (the real ones distinct: the id is in them): a key's place is the number below it
+        for (int i = tid; i < Q_WAVES * kout; i += Q_THREADS) {
+            const uint64_t v = s_top[(i / kout) * KTH_MAX_K + i % kout];
+            if (v == ~0ull) continue;
+            int below = 0;
+            for (int j = 0; j < Q_WAVES * kout; j++) below += s_top[(j / kout) * KTH_MAX_K + j % kout] < v ? 1 : 0;
+            if (below < kout) emit(below, v);
+        }
+    } else {
+        uint64_t prev = 0;
+        for (int r = 0; r < kout; r++) {
+            uint64_t best = ~0ull;
+            for (int c = tid; c < nsel; c += Q_THREADS) {
+                const uint64_t kk = keys[c];
+                if ((r == 0 || kk > prev) && kk < best) best = kk;
+            }
+            best = block_min_u64(best, s_red, tid);
+            if (tid == 0) emit(r, best);
+            prev = best;
+        }
+    }
+    for (int r = kout + tid; r < P.k; r += Q_THREADS) {
+        P.ids_out[qi * P.k + r] = -1;
+        P.dist_out[qi * P.k + r] = INFINITY;
+    }
+    if (tid == 0) P.count_out[qi] = kout;
+}
+
 // ---- filter dots of a whole batch on the matrix cores ----------------------------------------------------------
 // scores[q][r] = sum_i g_q[i] y_r[i] for ALL rows r and all queries q of the batch, from the fp16 images: a
 // nq x N x dpad contraction that reads the fp16 matrix once (0.3 GB at 50k x 3000) where the per-query form gathers
@@ -529,7 +714,9 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
     // query has many more candidates than results.  MORNA_QUERY_DENSE=0 keeps the per-candidate gather form.
     static const bool filter_on = !(getenv("MORNA_QUERY_FILTER") && atoi(getenv("MORNA_QUERY_FILTER")) == 0);
     static const bool dense_on = !(getenv("MORNA_QUERY_DENSE") && atoi(getenv("MORNA_QUERY_DENSE")) == 0);
-    const bool use_filter = filter_on && cap > 4 * (int64_t)k;
+    // fewer queries than would give every CU a workgroup: the spread form (MORNA_QUERY_SPREAD=0: one workgroup per query)
+    const bool spread = nq < 64 && !(getenv("MORNA_QUERY_SPREAD") && atoi(getenv("MORNA_QUERY_SPREAD")) == 0);
+    const bool use_filter = !spread && filter_on && cap > 4 * (int64_t)k;
     // the whole-batch contraction reads every fp16 row once; the gather form reads min(cap, ~K) rows per query
     auto dense_pays = [&](int64_t nb) { return nb >= 64 && nb * std::min<int64_t>(cap, h->K) >= 2 * N; };
     const bool may_dense = use_filter && dense_on && dense_pays(nq);
@@ -599,7 +786,23 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
             HIP_TRY(hipMemcpyAsync(d_items, items_host + q0, (size_t)nb * 4, hipMemcpyHostToDevice, h->stream));
             P.items = d_items;
         }
-        {
+        if (spread) {
+            // a batch too small to fill the chip with one workgroup per query: each query's work is dealt out (kernels above)
+            ScopedTimer tm(h, MORNA_T_QUERY, 0);
+            hipLaunchKernelGGL(query_roots_kernel, dim3((unsigned)((h->n_trees + Q_WAVES - 1) / Q_WAVES), (unsigned)nb), dim3(Q_THREADS), 0,
+                               h->stream, P);
+            if (bm_lds) {
+                const size_t bl = (size_t)bm_words * 4;
+                if (bl > 48 * 1024)
+                    HIP_TRY(hipFuncSetAttribute((const void *)query_descend_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bl));
+                hipLaunchKernelGGL(query_descend_kernel<true>, dim3((unsigned)nb), dim3(WAVE), bl, h->stream, P);
+            } else {
+                hipLaunchKernelGGL(query_descend_kernel<false>, dim3((unsigned)nb), dim3(WAVE), 0, h->stream, P);
+            }
+            hipLaunchKernelGGL(query_cand_dots_kernel, dim3((unsigned)((cap + Q_WAVES * QS_CPW - 1) / (Q_WAVES * QS_CPW)), (unsigned)nb),
+                               dim3(Q_THREADS), 0, h->stream, P);
+            hipLaunchKernelGGL(query_topk_kernel, dim3((unsigned)nb), dim3(Q_THREADS), 0, h->stream, P);
+        } else {
             // algorithmic bytes = 4*D*(hyperplane dots + unique candidates + 1) per
             // query; the kernel counts them into d_stat[0], resolve_timers() prices them
             ScopedTimer tm(h, MORNA_T_QUERY, 0);

@@ -116,10 +116,22 @@ def test_c3_queries_distances_and_recall_vs_exact(c3):
         assert (np.diff(d[qi]) >= 0).all() and len(set(ids[qi].tolist())) == K3
     # an answer does not depend on which queries share its batch: 1000 at once go through the 256 x 256 form of the filter
     # contraction (whole rounds of the chip) + the 128 x 128 form for the rows behind, 400 at once through the 128 x 128
-    # form alone, 40 at once through the per-candidate form -- three different filters, one result
-    for part in (400, 40):
+    # form alone, 40 / 8 / 1 at once through the spread form (a query's root margins and candidate dots dealt out over the
+    # chip, canonical dots for every candidate) -- and 40 through the one-workgroup-per-query form it replaces for small
+    # batches (per-candidate fp16 filter): four different routes, one result
+    for part in (400, 40, 8, 1):
         pi, pd, pc = a.get_nns_by_item_batch(items[:part], K3, SEARCH_K)
         assert pi.tolist() == ids[:part].tolist() and pd.tobytes() == d[:part].tobytes() and pc.tolist() == cnt[:part].tolist(), part
+    os.environ["MORNA_QUERY_SPREAD"] = "0"
+    try:
+        pi, pd, pc = a.get_nns_by_item_batch(items[:40], K3, SEARCH_K)
+    finally:
+        del os.environ["MORNA_QUERY_SPREAD"]
+    assert pi.tolist() == ids[:40].tolist() and pd.tobytes() == d[:40].tobytes() and pc.tolist() == cnt[:40].tolist()
+    # by vector, one query at a time (what `morna search` does): the stored row as the query vector
+    for qi in (0, 17, 333):
+        one = a.get_nns_by_vector(X[items[qi]].tolist(), K3, SEARCH_K, include_distances=True)
+        assert one[0] == ids[qi].tolist() and np.array(one[1], np.float32).tobytes() == d[qi].tobytes()
     eids, ed, ecnt = a.exact_search_batch(X[items].astype(np.float64), K3)
     assert (ecnt == K3).all()
     recall = np.mean([len(set(ids[i].tolist()) & set(eids[i].tolist())) / float(K3) for i in range(Q3)])
