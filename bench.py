@@ -191,12 +191,19 @@ def query_sweep(args, index, items, k, st):
         e = {"nq": nq, "ms_per_call": ms, "us_per_query": 1e3 * ms / nq, "kernels_ms": tq["ms"],
              "rows_touched_per_query": rows,
              "path": "whole-batch fp16 contraction + traversal" if (nq >= 64 and nq * min(st["leaf_capacity"], rows) >= 2 * st["n_items"])
-                     else "per-candidate fp16 filter (gather)"}
+                     else "spread: a wave per (query, tree) root margin, one wave descends, a wave per candidate (canonical fp32 dot), "
+                          "one workgroup ranks" if nq < 64 else "one workgroup per query, per-candidate fp16 filter"}
         if nq == 1:
             floor_b = cand * dp * 2 + dots * dp * 4
+            moved_b = cand * dp * 4 + dots * dp * 4        # the spread form reads the candidates' fp32 rows (no fp16 filter stage)
+            pops = rows - cand - 1 - st["n_trees"]         # hyperplane dots below the roots: one dependent pop each
             e["byte_floor"] = {"bytes": floor_b, "us_at_hbm_peak": floor_b / (HBM_PEAK_GBS * 1e3),
-                               "kernel_us": 1e3 * tq["ms"], "kernel_over_floor": 1e3 * tq["ms"] / max(floor_b / (HBM_PEAK_GBS * 1e3), 1e-9),
-                               "what": "%.0f candidates x %d B (fp16 rows) + %d hyperplanes x %d B" % (cand, dp * 2, dots, dp * 4)}
+                               "bytes_moved": moved_b, "kernel_us": 1e3 * tq["ms"],
+                               "kernel_over_floor": 1e3 * tq["ms"] / max(floor_b / (HBM_PEAK_GBS * 1e3), 1e-9),
+                               "what": "%.0f candidates x %d B (fp16 rows) + %d hyperplanes x %d B" % (cand, dp * 2, dots, dp * 4),
+                               "latency_chain": "%.0f dependent pops below the roots (queue maximum -> node record + hyperplane -> "
+                                                "canonical dot -> push), then one leaf: the chain, not the bytes, is what a "
+                                                "lone query waits for" % pops}
         out["nq_%d" % nq] = e
     return out
 

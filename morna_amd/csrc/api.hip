@@ -169,6 +169,8 @@ int morna_index_destroy(morna_index *h)
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->host_counts) (void)hipHostFree(h->host_counts);
     if (h->host_out) (void)hipHostFree(h->host_out);
+    if (h->host_small) (void)hipHostFree(h->host_small);
+    if (h->host_q) (void)hipHostFree(h->host_q);
     if (h->host_tables) (void)hipHostFree(h->host_tables);
     hipStream_t s = h->stream, s2 = h->stream2;
     delete h;   // DevBuf destructors free HBM

@@ -135,6 +135,10 @@ struct morna_index {
     uint32_t count_epoch = 0;
     uint8_t *host_out = nullptr;       // page-locked staging of query results
     size_t host_out_cap = 0;
+    uint8_t *host_small = nullptr;     // page-locked, device-visible: the answers of a small query batch, written by the kernel itself
+    size_t host_small_cap = 0;
+    uint8_t *host_q = nullptr;         // page-locked staging of a small batch's query vectors, padded to the row stride
+    size_t host_q_cap = 0;
     uint8_t *host_tables = nullptr;    // page-locked staging of the node tables on their way to HBM (forest.hip)
     size_t host_tables_cap = 0;
 

@@ -357,6 +357,37 @@ __device__ inline uint64_t wave_min_u64(uint64_t v)
     }
     return v;
 }
+// The wave's maximum without LDS round trips (v_permlane32_swap, v_permlane16_swap, DPP row shifts instead of the twelve
+// ds_bpermute of the butterfly below); 0 is the identity (lanes shifted in from outside a row read 0).  Every lane gets it.
+__device__ inline uint64_t wave_max_u64_fast(uint64_t v)
+{
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    auto take = [&](uint32_t olo, uint32_t ohi) {
+        const uint64_t o = ((uint64_t)ohi << 32) | olo, m = ((uint64_t)hi << 32) | lo;
+        if (o > m) { lo = olo; hi = ohi; }
+    };
+    {
+        const u32x2 a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        take(a[1], b[1]);   // lanes 0-31: lanes 32-63
+    }
+    {
+        const u32x2 a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        take(a[1], b[1]);   // rows 0 / 2: rows 1 / 3
+    }
+#define MORNA_DPP_MAX(CTRL)                                                                        \
+    take((uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, 0xf, 0xf, true),                  \
+         (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, 0xf, 0xf, true))
+    MORNA_DPP_MAX(0x108);   // row_shl:8
+    MORNA_DPP_MAX(0x104);
+    MORNA_DPP_MAX(0x102);
+    MORNA_DPP_MAX(0x101);
+#undef MORNA_DPP_MAX
+    lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+    hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ inline uint64_t wave_max_u64(uint64_t v)
 {
 #pragma unroll

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 #include "common.hpp"
 #include "devutil.hpp"
@@ -36,12 +37,15 @@ struct QueryParams {
     int64_t n_nodes;
     const float *Q;            // [nq][dpad] or null
     const int32_t *items;      // [nq] or null
+    int32_t n_inline;          // spread form, by item, up to 16 queries: the item numbers travel with the launch (no copy)
+    int32_t inline_items[16];
     int32_t k, search_k;
     int32_t cap;               // candidate capacity per query
     int32_t bm_words;
     // workspace, one slice per query
     uint64_t *pq;              // [nq][n_nodes]
     int32_t *cand;             // [nq][cap]
+    int64_t *cand_off;         // [nq] spread form: >= 0: the candidates are perm[cand_off .. + ncand) (one leaf, not copied); -1: cand[]
     uint64_t *keys;            // [nq][cap]
     float *low;                // [nq][cap] lower bound of a candidate's distance (filter modes)
     int32_t *ncand;            // [nq] unique candidates found by the traversal (may exceed cap)
@@ -70,6 +74,14 @@ struct QueryParams {
 __device__ inline uint64_t pq_key(float d, int32_t node)
 {
     return ((uint64_t)f32_orderable(d) << 32) | (uint32_t)node;
+}
+
+// the query's row (spread kernels): a stored row -- its number from the launch arguments or from the items array -- or a
+// row of the staged query vectors
+__device__ inline const float4 *query_row(const QueryParams &P, int64_t qi)
+{
+    if (P.n_inline) return (const float4 *)(P.X + (int64_t)P.inline_items[qi] * P.dpad);
+    return P.items ? (const float4 *)(P.X + (int64_t)P.items[qi] * P.dpad) : (const float4 *)(P.Q + qi * P.dpad);
 }
 
 // block-wide min of a uint64 (all threads get the result)
@@ -242,7 +254,7 @@ __global__ __launch_bounds__(Q_THREADS) void query_roots_kernel(QueryParams P)
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const int64_t qi = blockIdx.y;
     const int nvec = P.dpad / 4;
-    const float4 *q = P.items ? (const float4 *)(P.X + (int64_t)P.items[qi] * P.dpad) : (const float4 *)(P.Q + qi * P.dpad);
+    const float4 *q = query_row(P, qi);
     if (blockIdx.x == 0 && w == Q_WAVES - 1) {
         const float pp = wave_dot(q, q, nvec, lane);
         if (lane == 0) P.qpp[qi] = pp;
@@ -258,79 +270,195 @@ __global__ __launch_bounds__(Q_THREADS) void query_roots_kernel(QueryParams P)
 }
 
 #define PQ_LDS 1024   // queue entries kept in LDS by the one-wave descent; entries beyond stay in the global array
-template <bool BM_LDS>
+// One wave per query.  A pop is a chain -- the entry with the largest bound, its node record, its hyperplane, one dot -- and
+// the descent is a chain of pops (five or six at morna's defaults), so what counts is the length of one: the queue sits in
+// LDS with the hyperplane slot of every entry beside it (the slot of a node is looked up when the node is PUSHED, under the
+// hyperplane fetch of its parent), so that the record and the hyperplane of a popped node are requested together: one
+// round trip to memory per pop instead of two; the maximum is taken with cross-lane moves; a leaf's ids are fetched eight
+// loads at a time, and the first leaf -- whose ids are distinct, a tree lists an item once -- is copied without touching the
+// bitmap when it ends the search (the case of search_k = 100 with leaves of ~K ids).
+// NV: float4 per lane of a row (dpad / 256) when the query fits the wave's registers -- it is then loaded ONCE and every
+// hyperplane is requested whole, all its 1-KiB pieces in flight together (a lone wave that keeps four loads in flight moves
+// ~13 GB/s: the 24 KB of a dot by wave_dot() took 2 us, most of a pop); 0: any row length, through wave_dot().  Same fmaf
+// chains either way.
+template <int NV>
+__device__ inline float wave_dot_held(const float4 *__restrict__ row, const float4 (&qr)[NV > 0 ? NV : 1], int lane)
+{
+    float4 x[NV > 0 ? NV : 1];
+#pragma unroll
+    for (int k = 0; k < NV; k++) x[k] = row[lane + WAVE * k];
+    Acc4 s = acc4_zero();
+#pragma unroll
+    for (int k = 0; k < NV; k++) fma4(s, x[k], qr[k]);
+    return acc4_finish(s);
+}
+
+template <bool BM_LDS, int NV>
 __global__ __launch_bounds__(WAVE) void query_descend_kernel(QueryParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint64_t s_pq[PQ_LDS];
+    __shared__ int32_t s_slot[PQ_LDS];   // hyperplane slot of the entry's node, -1: a leaf
     __shared__ int s_ncand;
     const int lane = threadIdx.x;
     const int64_t qi = blockIdx.x;
     const int nvec = P.dpad / 4;
     const int T = P.n_trees;
     uint32_t *bm = BM_LDS ? (uint32_t *)smem : P.bm_global + (size_t)qi * P.bm_words;
-    const float4 *q = P.items ? (const float4 *)(P.X + (int64_t)P.items[qi] * P.dpad) : (const float4 *)(P.Q + qi * P.dpad);
+    const float4 *q = query_row(P, qi);
     uint64_t *gpq = P.pq + qi * P.n_nodes;
     int32_t *cand = P.cand + qi * P.cap;
     const bool roots_split = P.n_items > P.K;
     int hn = roots_split ? 2 * T : T;
-    for (int i = lane; i < P.bm_words; i += WAVE) bm[i] = 0u;
-    for (int i = lane; i < hn && i < PQ_LDS; i += WAVE) s_pq[i] = roots_split ? gpq[i] : pq_key(INFINITY, i);
+#ifdef MORNA_DESCEND_PROBE
+    long long tp[40];
+    int ntp = 0;
+#define TP() do { if (ntp < 40) tp[ntp++] = clock64(); } while (0)
+#else
+#define TP() do { } while (0)
+#endif
+    TP();
+    float4 qr[NV > 0 ? NV : 1];
+#pragma unroll
+    for (int k = 0; k < NV; k++) qr[k] = q[lane + WAVE * k];
+    {
+        // the queue as the root margins left it, and the hyperplane slot of every entry's node: all the loads of a phase in
+        // flight together (written as one loop, every iteration waited for its two dependent round trips)
+        uint64_t k16[PQ_LDS / WAVE];
+        int32_t s16[PQ_LDS / WAVE];
+#pragma unroll
+        for (int u = 0; u < PQ_LDS / WAVE; u++) {
+            const int i = lane + WAVE * u;
+            k16[u] = i < hn ? (roots_split ? gpq[i] : pq_key(INFINITY, i)) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < PQ_LDS / WAVE; u++) s16[u] = lane + WAVE * u < hn ? P.node_hp[(int32_t)(uint32_t)k16[u]] : -1;
+#pragma unroll
+        for (int u = 0; u < PQ_LDS / WAVE; u++) {
+            s_pq[lane + WAVE * u] = k16[u];       // (0 beyond hn: an empty slot)
+            s_slot[lane + WAVE * u] = s16[u];
+        }
+    }
     if (!roots_split)
         for (int i = PQ_LDS + lane; i < hn; i += WAVE) gpq[i] = pq_key(INFINITY, i);
+    for (int i = lane; i < P.bm_words; i += WAVE) bm[i] = 0u;
     if (lane == 0) s_ncand = 0;
     __syncthreads();   // (one wave: orders the LDS / global initialisation in front of the loop)
-    int ndots = roots_split ? T : 0;
-    int64_t nn = 0;
+    int ndots = roots_split ? T : 0, n_leaves = 0;
+    int64_t nn = 0, cand_off = -1;
     const int64_t search_k = P.search_k;
+    TP();
     while (nn < search_k) {
         uint64_t best = 0;
         int bestpos = -1;
-        for (int i = lane; i < hn; i += WAVE) {
-            const uint64_t kk = i < PQ_LDS ? s_pq[i] : gpq[i];
+        {
+            // (slots beyond hn hold 0; a lone wave issues an instruction every ~4 cycles, so the scan is its instruction count:
+            // eight entries per lane while the queue is that short -- 200 trees give 400 entries + 2 per pop)
+            auto scan = [&](auto NU) {
+                constexpr int nu = decltype(NU)::value;
+                uint64_t kk[nu];
+#pragma unroll
+                for (int u = 0; u < nu; u++) kk[u] = s_pq[lane + WAVE * u];
+#pragma unroll
+                for (int u = 0; u < nu; u++)
+                    if (kk[u] > best) { best = kk[u]; bestpos = lane + WAVE * u; }
+            };
+            if (hn <= 8 * WAVE) scan(std::integral_constant<int, 8>());
+            else scan(std::integral_constant<int, PQ_LDS / WAVE>());
+        }
+        for (int i = PQ_LDS + lane; i < hn; i += WAVE) {
+            const uint64_t kk = gpq[i];
             if (kk > best) { best = kk; bestpos = i; }
         }
-        const uint64_t top = wave_max_u64(best);
+        const uint64_t top = wave_max_u64_fast(best);
+        TP();
         if (top == 0) break;                       // queue empty
-        if (best == top && bestpos >= 0) {         // exactly one lane owns it
-            if (bestpos < PQ_LDS) s_pq[bestpos] = 0;
-            else gpq[bestpos] = 0;
+        const unsigned long long owners = __ballot(best == top && bestpos >= 0);   // exactly one lane (keys are distinct)
+        const int pos = __builtin_amdgcn_readlane(bestpos, __ffsll((long long)owners) - 1);
+        if (lane == 0) {
+            if (pos < PQ_LDS) s_pq[pos] = 0;
+            else gpq[pos] = 0;
         }
         const int32_t node = (int32_t)(uint32_t)top;
         const float d = f32_from_orderable((uint32_t)(top >> 32));
+        const int32_t slot = pos < PQ_LDS ? s_slot[pos] : P.node_hp[node];
         const int4 rec = *(const int4 *)(P.node_rec + 4 * (int64_t)node);   // child0, child1, start, count
-        if (rec.x < 0) {
+        if (slot < 0) {
+            // leaf: nns.insert(all ids); duplicates across trees are dropped by the bitmap
             const int32_t *src_ids = P.perm + (int64_t)P.node_tree[node] * P.n_items + rec.z;
-            for (int i = lane; i < rec.w; i += WAVE) {
-                const int32_t id = src_ids[i];
-                const uint32_t bit = 1u << (id & 31);
-                const uint32_t old = atomicOr(&bm[id >> 5], bit);
-                if (!(old & bit)) {
-                    const int slot = atomicAdd(&s_ncand, 1);
-                    if (slot < P.cap) cand[slot] = id;
+            const int count = rec.w;
+            if (n_leaves == 0 && nn + count >= search_k) {
+                // the first leaf ends the search: its ids ARE the candidates (distinct: a tree lists an item once) -- not copied
+                if (lane == 0) {
+                    s_ncand = count;
+                    cand_off = (int64_t)P.node_tree[node] * P.n_items + rec.z;
+                }
+            } else {
+                for (int base = 0; base < count; base += 8 * WAVE) {
+                    int32_t idv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int i = base + u * WAVE + lane;
+                        idv[u] = i < count ? src_ids[i] : -1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        bool fresh = false;
+                        if (idv[u] >= 0) {
+                            const uint32_t bit = 1u << (idv[u] & 31);
+                            fresh = !(atomicOr(&bm[idv[u] >> 5], bit) & bit);
+                        }
+                        const unsigned long long mask = __ballot(fresh);
+                        if (mask) {   // one counter update per 64 ids: the fresh ones take consecutive slots
+                            int first = 0;
+                            if (lane == 0) first = atomicAdd(&s_ncand, __popcll(mask));
+                            first = __builtin_amdgcn_readfirstlane(first);
+                            const int slot_c = first + __popcll(mask & ((1ull << lane) - 1ull));
+                            if (fresh && slot_c < P.cap) cand[slot_c] = idv[u];
+                        }
+                    }
                 }
             }
-            nn += rec.w;
+            nn += count;
+            n_leaves++;
         } else {
-            const float m = wave_dot((const float4 *)(P.hp + (int64_t)P.node_hp[node] * P.dpad), q, nvec, lane);
-            if (lane == 0) {
-                const uint64_t k1 = pq_key(d < m ? d : m, rec.y), k0 = pq_key(d < -m ? d : -m, rec.x);
-                if (hn < PQ_LDS) s_pq[hn] = k1; else gpq[hn] = k1;
-                if (hn + 1 < PQ_LDS) s_pq[hn + 1] = k0; else gpq[hn + 1] = k0;
+            // the children's slots are wanted when they are popped, not now: requested here, under the hyperplane fetch
+            const int32_t slot_c = lane < 2 ? P.node_hp[lane == 0 ? rec.y : rec.x] : 0;
+            const float4 *hrow = (const float4 *)(P.hp + (int64_t)slot * P.dpad);
+            const float m = NV > 0 ? wave_dot_held<NV>(hrow, qr, lane) : wave_dot(hrow, q, nvec, lane);
+            if (lane < 2) {
+                const uint64_t key = lane == 0 ? pq_key(d < m ? d : m, rec.y) : pq_key(d < -m ? d : -m, rec.x);
+                if (hn + lane < PQ_LDS) {
+                    s_pq[hn + lane] = key;
+                    s_slot[hn + lane] = slot_c;
+                } else {
+                    gpq[hn + lane] = key;
+                }
             }
             hn += 2;
             ndots++;
         }
         __syncthreads();   // one wave: the queue writes above are seen by the next scan
+        TP();
     }
     if (lane == 0) {
         const int nc = s_ncand;
         P.ncand[qi] = nc;
+        P.cand_off[qi] = cand_off;
         atomicAdd(P.stat, (unsigned long long)(ndots + (nc < P.cap ? nc : P.cap) + 1));
     }
+#ifdef MORNA_DESCEND_PROBE
+    TP();
+    if (lane == 0 && qi == 0) {
+        float *o = P.low + 2 * gridDim.x + 16;
+        o[0] = (float)ntp;
+        for (int i = 1; i < ntp; i++) o[i] = (float)(tp[i] - tp[i - 1]);
+    }
+#endif
+#undef TP
 }
 
-#define QS_CPW 2   // candidates per wave of query_cand_dots_kernel
+#define QS_CPW 1   // candidates per wave of query_cand_dots_kernel
 __global__ __launch_bounds__(Q_THREADS) void query_cand_dots_kernel(QueryParams P)
 {
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
@@ -339,8 +467,9 @@ __global__ __launch_bounds__(Q_THREADS) void query_cand_dots_kernel(QueryParams 
     const int ncand = P.ncand[qi] < P.cap ? P.ncand[qi] : P.cap;
     const int c0 = (blockIdx.x * Q_WAVES + w) * QS_CPW;
     if (c0 >= ncand) return;
-    const float4 *q = P.items ? (const float4 *)(P.X + (int64_t)P.items[qi] * P.dpad) : (const float4 *)(P.Q + qi * P.dpad);
-    const int32_t *cand = P.cand + qi * P.cap;
+    const float4 *q = query_row(P, qi);
+    const int64_t off = P.cand_off[qi];
+    const int32_t *cand = off >= 0 ? P.perm + off : P.cand + qi * P.cap;
     uint64_t *keys = P.keys + qi * P.cap;
     const float pp = P.qpp[qi];
 #pragma unroll
@@ -354,14 +483,19 @@ __global__ __launch_bounds__(Q_THREADS) void query_cand_dots_kernel(QueryParams 
     }
 }
 
-// the k smallest (distance, id) keys of a query's candidates, in order: every wave extracts the k smallest of its share in
-// registers (no barrier), the waves' lists are merged by counting
+// The k smallest (distance, id) keys of a query's candidates, in order.  Two looks at the keys instead of k rounds of a
+// block-wide minimum: every thread's own minimum -- the k-th smallest of those 256 bounds the k-th smallest key from above --,
+// then the few keys at or below that bound are collected and ranked by counting (the keys are distinct: the id is in them).
 #define QT_HELD 16
+#define QT_LIST 1024
 __global__ __launch_bounds__(Q_THREADS) void query_topk_kernel(QueryParams P)
 {
     __shared__ uint64_t s_red[Q_WAVES];
-    __shared__ uint64_t s_top[Q_WAVES * KTH_MAX_K];
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    __shared__ uint64_t s_min[Q_THREADS];
+    __shared__ uint64_t s_list[QT_LIST];
+    __shared__ uint64_t s_bound;
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
     const int64_t qi = blockIdx.x;
     const uint64_t *keys = P.keys + qi * P.cap;
     const int nsel = P.ncand[qi] < P.cap ? P.ncand[qi] : P.cap;
@@ -371,29 +505,45 @@ __global__ __launch_bounds__(Q_THREADS) void query_topk_kernel(QueryParams P)
         const float d = f32_from_orderable((uint32_t)(key >> 32));
         P.dist_out[qi * P.k + r] = sqrtf(d > 0.f ? d : 0.f);   // normalized_distance
     };
-    if (nsel <= Q_THREADS * QT_HELD && P.k <= KTH_MAX_K) {
-        uint64_t held[QT_HELD];
+    bool done = false;
+    if (nsel <= Q_THREADS * QT_HELD && kout > 0 && kout <= Q_THREADS) {
+        uint64_t held[QT_HELD], mine = ~0ull;
 #pragma unroll
-        for (int u = 0; u < QT_HELD; u++) held[u] = tid + Q_THREADS * u < nsel ? keys[tid + Q_THREADS * u] : ~0ull;
-        uint64_t prev = 0;
-        for (int r = 0; r < kout; r++) {
-            uint64_t best = ~0ull;
-#pragma unroll
-            for (int u = 0; u < QT_HELD; u++)
-                if ((r == 0 || held[u] > prev) && held[u] < best) best = held[u];
-            prev = wave_min_u64(best);
-            if (lane == 0) s_top[w * KTH_MAX_K + r] = prev;   // ~0: this wave has run out of keys
+        for (int u = 0; u < QT_HELD; u++) {
+            held[u] = tid + Q_THREADS * u < nsel ? keys[tid + Q_THREADS * u] : ~0ull;
+            mine = held[u] < mine ? held[u] : mine;
+        }
+        s_min[tid] = mine;
+        if (tid == 0) { s_n = 0; s_bound = ~0ull; }
+        __syncthreads();
+        if (nsel <= Q_THREADS) {
+            if (tid == 0) s_bound = ~0ull - 1;   // a key per thread at most: all of them are collected
+        } else {
+            int below = 0;
+            for (int j = 0; j < Q_THREADS; j++) below += s_min[j] < mine ? 1 : 0;
+            if (mine != ~0ull && below == kout - 1) s_bound = mine;   // kout threads hold a key at or below it
         }
         __syncthreads();
-        // Q_WAVES sorted lists of kout keys (the real ones distinct: the id is in them): a key's place is the number below it
-        for (int i = tid; i < Q_WAVES * kout; i += Q_THREADS) {
-            const uint64_t v = s_top[(i / kout) * KTH_MAX_K + i % kout];
-            if (v == ~0ull) continue;
-            int below = 0;
-            for (int j = 0; j < Q_WAVES * kout; j++) below += s_top[(j / kout) * KTH_MAX_K + j % kout] < v ? 1 : 0;
-            if (below < kout) emit(below, v);
+        const uint64_t bound = s_bound;
+#pragma unroll
+        for (int u = 0; u < QT_HELD; u++)
+            if (held[u] <= bound && held[u] != ~0ull) {
+                const int slot = atomicAdd(&s_n, 1);
+                if (slot < QT_LIST) s_list[slot] = held[u];
+            }
+        __syncthreads();
+        const int m = s_n;
+        if (m <= QT_LIST) {
+            for (int i = tid; i < m; i += Q_THREADS) {
+                const uint64_t v = s_list[i];
+                int below = 0;
+                for (int j = 0; j < m; j++) below += s_list[j] < v ? 1 : 0;
+                if (below < kout) emit(below, v);
+            }
+            done = true;
         }
-    } else {
+    }
+    if (!done) {   // more keys than the registers hold, or a tie of thousands at the bound: k rounds of a block-wide minimum
         uint64_t prev = 0;
         for (int r = 0; r < kout; r++) {
             uint64_t best = ~0ull;
@@ -764,6 +914,7 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
         P.count_out = (int32_t *)p; p += s_qf;
         float *scores = (float *)p; p += s_scores;
         P.stat = h->d_stat.p;
+        P.cand_off = (int64_t *)P.low;   // (the spread form has no lower bounds: the array's first 8 bytes per query)
         P.X16 = nullptr; P.xscale = nullptr; P.xn16 = P.xe16 = nullptr; P.delta = 0.f;
         P.scores = nullptr; P.qscale = P.qn16 = P.qe16 = nullptr; P.eacc = P.eacc_big = 0.f; P.big_rows = 0;
         if (use_filter) {
@@ -777,28 +928,107 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
             P.eacc = mm16_eacc(h->dpad);
         }
         P.Q = nullptr; P.items = nullptr;
+        P.n_inline = 0;
+        if (spread && !q_host && nb <= 16) {
+            P.n_inline = (int32_t)nb;
+            for (int64_t i = 0; i < nb; i++) P.inline_items[i] = items_host[q0 + i];
+        } else
         if (q_host) {
-            HIP_TRY(hipMemsetAsync(Qd, 0, (size_t)nb * h->dpad * 4, h->stream));
-            HIP_TRY(hipMemcpy2DAsync(Qd, (size_t)h->dpad * 4, q_host + q0 * q_stride, (size_t)q_stride * 4,
-                                     (size_t)h->dim * 4, (size_t)nb, hipMemcpyDefault, h->stream));
+            bool staged = false;
+            if (spread && ids_out && !packed_dev) {   // (the batch ends with a host wait: the staging buffer is free again by then)
+                // a few query vectors from host memory: padded on the host into page-locked memory and sent as ONE copy (a
+                // memset + a 2-D copy out of pageable memory are two stream operations of ~10 us each)
+                hipPointerAttribute_t at;
+                const bool on_host = hipPointerGetAttributes(&at, q_host) != hipSuccess || at.type == hipMemoryTypeHost ||
+                                     at.type == hipMemoryTypeUnregistered;
+                (void)hipGetLastError();   // (an unregistered host pointer reports an error on some runtimes)
+                if (on_host) {
+                    const size_t need = (size_t)nb * h->dpad * 4;
+                    if (need > h->host_q_cap) {
+                        if (h->host_q) (void)hipHostFree(h->host_q);
+                        h->host_q = nullptr;
+                        h->host_q_cap = 0;
+                        HIP_TRY(hipHostMalloc((void **)&h->host_q, need * 2, hipHostMallocDefault));
+                        h->host_q_cap = need * 2;
+                    }
+                    float *hq = (float *)h->host_q;
+                    for (int64_t i = 0; i < nb; i++) {
+                        memcpy(hq + i * h->dpad, q_host + (q0 + i) * q_stride, (size_t)h->dim * 4);
+                        memset(hq + i * h->dpad + h->dim, 0, (size_t)(h->dpad - h->dim) * 4);
+                    }
+                    HIP_TRY(hipMemcpyAsync(Qd, hq, need, hipMemcpyHostToDevice, h->stream));
+                    staged = true;
+                }
+            }
+            if (!staged) {
+                HIP_TRY(hipMemsetAsync(Qd, 0, (size_t)nb * h->dpad * 4, h->stream));
+                HIP_TRY(hipMemcpy2DAsync(Qd, (size_t)h->dpad * 4, q_host + q0 * q_stride, (size_t)q_stride * 4,
+                                         (size_t)h->dim * 4, (size_t)nb, hipMemcpyDefault, h->stream));
+            }
             P.Q = Qd;
         } else {
             HIP_TRY(hipMemcpyAsync(d_items, items_host + q0, (size_t)nb * 4, hipMemcpyHostToDevice, h->stream));
             P.items = d_items;
+        }
+        // spread form, answers wanted on the host: the last kernel writes them straight into page-locked memory of the handle
+        // (a copy out of HBM is another ~8 us operation on the stream for 160 bytes per query)
+        const bool direct = spread && ids_out && !packed_dev;
+        if (direct) {
+            const size_t need = 2 * s_ids + s_qf;
+            if (need > h->host_small_cap) {
+                if (h->host_small) (void)hipHostFree(h->host_small);
+                h->host_small = nullptr;
+                h->host_small_cap = 0;
+                HIP_TRY(hipHostMalloc((void **)&h->host_small, need * 2, hipHostMallocMapped | hipHostMallocCoherent));
+                h->host_small_cap = need * 2;
+            }
+            uint8_t *dp = nullptr;
+            HIP_TRY(hipHostGetDevicePointer((void **)&dp, h->host_small, 0));
+            P.ids_out = (int32_t *)dp;
+            P.dist_out = (float *)(dp + s_ids);
+            P.count_out = (int32_t *)(dp + 2 * s_ids);
         }
         if (spread) {
             // a batch too small to fill the chip with one workgroup per query: each query's work is dealt out (kernels above)
             ScopedTimer tm(h, MORNA_T_QUERY, 0);
             hipLaunchKernelGGL(query_roots_kernel, dim3((unsigned)((h->n_trees + Q_WAVES - 1) / Q_WAVES), (unsigned)nb), dim3(Q_THREADS), 0,
                                h->stream, P);
-            if (bm_lds) {
-                const size_t bl = (size_t)bm_words * 4;
-                if (bl > 48 * 1024)
-                    HIP_TRY(hipFuncSetAttribute((const void *)query_descend_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bl));
-                hipLaunchKernelGGL(query_descend_kernel<true>, dim3((unsigned)nb), dim3(WAVE), bl, h->stream, P);
-            } else {
-                hipLaunchKernelGGL(query_descend_kernel<false>, dim3((unsigned)nb), dim3(WAVE), 0, h->stream, P);
+            const size_t bl = bm_lds ? (size_t)bm_words * 4 : 0;
+#define DESCEND(NVV)                                                                                                              \
+    do {                                                                                                                          \
+        if (bm_lds) {                                                                                                             \
+            if (bl > 32 * 1024)                                                                                                   \
+                HIP_TRY(hipFuncSetAttribute((const void *)query_descend_kernel<true, NVV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                            (int)bl));                                                                            \
+            hipLaunchKernelGGL((query_descend_kernel<true, NVV>), dim3((unsigned)nb), dim3(WAVE), bl, h->stream, P);              \
+        } else {                                                                                                                  \
+            hipLaunchKernelGGL((query_descend_kernel<false, NVV>), dim3((unsigned)nb), dim3(WAVE), 0, h->stream, P);              \
+        }                                                                                                                         \
+    } while (0)
+            switch (h->dpad / 256) {   // float4 per lane of a row
+            case 1: DESCEND(1); break;
+            case 2: DESCEND(2); break;
+            case 3: DESCEND(3); break;
+            case 4: DESCEND(4); break;
+            case 6: DESCEND(6); break;
+            case 8: DESCEND(8); break;
+            case 12: DESCEND(12); break;
+            case 16: DESCEND(16); break;
+            case 24: DESCEND(24); break;
+            case 32: DESCEND(32); break;
+            default: DESCEND(0); break;
             }
+#undef DESCEND
+#ifdef MORNA_DESCEND_PROBE
+            {
+                float probe[40];
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                HIP_TRY(hipMemcpy(probe, P.low + 2 * nb + 16, sizeof(probe), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[descend probe] cycles:");
+                for (int i = 1; i < (int)probe[0] && i < 40; i++) fprintf(stderr, " %.0f", probe[i]);
+                fprintf(stderr, "\n");
+            }
+#endif
             hipLaunchKernelGGL(query_cand_dots_kernel, dim3((unsigned)((cap + Q_WAVES * QS_CPW - 1) / (Q_WAVES * QS_CPW)), (unsigned)nb),
                                dim3(Q_THREADS), 0, h->stream, P);
             hipLaunchKernelGGL(query_topk_kernel, dim3((unsigned)nb), dim3(Q_THREADS), 0, h->stream, P);
@@ -880,7 +1110,12 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
                                P.dist_out, nb * k, k, (int32_t)id_offset, packed_dev + q0 * 2 * k);
             HIP_TRY(hipGetLastError());
         }
-        if (ids_out) {
+        if (direct) {
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            memcpy(ids_out + q0 * k, h->host_small, (size_t)nb * k * 4);
+            if (dist_out) memcpy(dist_out + q0 * k, h->host_small + s_ids, (size_t)nb * k * 4);
+            if (count_out) memcpy(count_out + q0, h->host_small + 2 * s_ids, (size_t)nb * 4);
+        } else if (ids_out) {
             // one copy of the whole result block into page-locked memory of the handle (three copies into the caller's
             // pageable arrays cost ~25 us of idle device each), then plain memcpys
             const size_t out_bytes = 2 * s_ids + s_qf;
