@@ -9,8 +9,8 @@
   configs[3]  rows cut into shards of ONE data set (global idf, global first-seen ids): the 50k set cut 8 ways in one
               process and 2 ways over two ranks (gloo, one device) -- stacked shard matrices byte-identical to the single
               index, sharded exact search identical, approximate recall not worse; a 25k x 3000 shard through
-              ShardedSearch on a 1-rank RCCL group (the 8-GPU run itself is the driver's; the 200k-sample set is cut by
-              scripts/c4_200k_shard.py, profiles/r03_c4_200k_shard.json).
+              ShardedSearch on a 1-rank RCCL group; the 200k-sample set itself cut 8 ways, one shard against the oracle's
+              matrix of the whole set (scripts/c4_200k_shard.py).  The 8-GPU run itself is the driver's.
   configs[4]  50k x 8192 exact all-pairs at its real size on one GPU (50 000 by-item queries x 50 000 rows, 32 sampled
               queries bit-exact against the oracle); one GPU's share of the 8-way cut (its 6250-row shard x all 50 000
               queries) through ShardedSearch on a 1-rank RCCL group; the 6250 x 6250 diagonal block.
@@ -302,8 +302,7 @@ def test_c4_shard_25k_through_sharded_search_one_rank_rccl(c3, capi):
     """configs[3]: what ONE GPU of a row-sharded index does -- a 25k x 3000 shard (the second half of the 50k data set cut
     two ways: global idf and ids, not a data set of its own) with its own 200-tree forest, queried through ShardedSearch
     on a 1-rank RCCL group (query rows stay in HBM, top-k all-gather over RCCL, merge kernel).  The 200k-sample set of
-    configs[3] itself is generated and cut 8 ways by scripts/c4_200k_shard.py (profiles/r03_c4_200k_shard.json): its host
-    generation takes minutes, too long for this suite."""
+    configs[3] itself is cut 8 ways in test_c4_200k_sample_set_cut_eight_ways_one_shard_vs_oracle below."""
     import torch
     import torch.distributed as dist
     from morna_amd.dist import ShardedSearch
@@ -336,6 +335,28 @@ def test_c4_shard_25k_through_sharded_search_one_rank_rccl(c3, capi):
             assert eids[qi].tolist() == rid.tolist() and ed[qi].tobytes() == rd.tobytes()
     finally:
         dist.destroy_process_group()
+
+
+def test_c4_200k_sample_set_cut_eight_ways_one_shard_vs_oracle():
+    """configs[3] at its stated size: ONE 200 000-sample data set, global pre-pass, cut into 8 row shards; shard 3
+    (25 000 rows) built on the GPU and compared byte for byte with rows 75 000 .. 100 000 of the oracle's matrix of the WHOLE
+    data set; its exact search against the oracle; a step through the in-library sharded path on a 1-rank RCCL
+    communicator (scripts/c4_200k_shard.py, whose output is kept as profiles/r03_c4_200k_shard.json).  In a process of its
+    own: 4e8 (sample, coverage) pairs take ~15 GB of host memory while the shard is cut."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "c4_200k_shard.py"), "3"], cwd=root, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout[r.stdout.index("{"):])
+    assert out["n_items"] == 200_000 and out["shard"] == {"rank": 3, "world": 8, "id_offset": 75_000, "rows": 25_000,
+                                                          "nnz": out["shard"]["nnz"], "lines": out["shard"]["lines"]}
+    assert out["shard_matrix_equals_rows_of_the_whole_oracle_matrix"] is True
+    assert out["exact_search_of_the_shard_equals_oracle"] is True
+    assert out["recall_at_20_vs_exact_within_the_shard"] >= 0.95
+    assert out["forest"]["max_depth"] >= 4            # ceil(log2(25000 / 3002)) = 4 (K = 3002)
 
 
 def test_c5_exact_all_pairs_shard_8192(capi):
