@@ -3,7 +3,7 @@
 lines, ~1e8 (sample, coverage) pairs, ~0.8 GB of text): what go_index (morna.py:824-865) costs from the file on disk to
 the saved index, stage by stage.  Never part of bench.py's `value` (that is measured with the lines resident in HBM).
 
-    python scripts/bench_e2e_index.py [--samples 50000] [--junctions 70000] [--trees 200] [--out profiles/r02_e2e_index.json]
+    python scripts/bench_e2e_index.py [--samples 50000] [--junctions 70000] [--trees 200] [--out profiles/r03_e2e_index.json]
 
 Stages timed:
   write     (setup, not part of indexing) the synthetic lines as text, plain and gzipped
@@ -123,6 +123,28 @@ def main():
         if r.returncode != 0:
             res["cli_stderr"] = r.stderr[-500:]
         res["samples_per_s_end_to_end_cli"] = a.samples / res["cli_index_wall_s"]
+        # ---- what the binary pre-tokenised cache buys: `index --cache` twice over the same file -- the first
+        # run parses and writes the cache, the second (other --n-trees, as a user tuning the index would) reads it back
+        cache = os.path.join(tmp, "lines.cache")
+        runs = {}
+        for name, trees in (("first_run_writes_cache", a.trees), ("second_run_reads_cache", max(a.trees // 2, 1))):
+            t0 = time.perf_counter()
+            r = subprocess.run([sys.executable, "-m", "morna_amd.cli", "index", "--intropolis", files["gz.tsv.gz"][0], "-x",
+                                os.path.join(tmp, "cli_" + name), "-s", str(a.samples), "--n-trees", str(trees), "--features",
+                                str(a.features), "--cache", cache], cwd=ROOT, capture_output=True, text=True)
+            runs[name] = {"wall_s": time.perf_counter() - t0, "rc": r.returncode, "n_trees": trees}
+        runs["cache_bytes"] = os.path.getsize(cache) if os.path.exists(cache) else None
+        t0 = time.perf_counter()
+        again = mindex.ParsedLines(files["gz.tsv.gz"][0], a.samples, 100, cache=cache)
+        runs["cache_load_s_in_process"] = time.perf_counter() - t0
+        runs["loaded_from_cache"] = bool(again.from_cache)
+        res["cli_index_with_cache"] = runs
+        # ---- the same file as 8 row shards built one after the other by one process (`index --shards 8`)
+        t0 = time.perf_counter()
+        r = subprocess.run([sys.executable, "-m", "morna_amd.cli", "index", "--intropolis", files["gz.tsv.gz"][0], "-x",
+                            os.path.join(tmp, "cli_shards"), "-s", str(a.samples), "--n-trees", str(a.trees), "--features",
+                            str(a.features), "--cache", cache, "--shards", "8"], cwd=ROOT, capture_output=True, text=True)
+        res["cli_index_8_shards_from_cache"] = {"wall_s": time.perf_counter() - t0, "rc": r.returncode}
     print(json.dumps(res, indent=1))
     if a.out:
         with open(a.out, "w") as fh:
