@@ -246,7 +246,9 @@ int morna_merge_topk_packed(morna_index *h, const int32_t *gathered_dev, int32_t
  *   morna_comm_unique_id   ncclGetUniqueId: ONE rank makes the id, the caller hands the 128 bytes to the others (any
  *                          channel: a file, MPI, torch.distributed's store)
  *   morna_comm_init        ncclCommInitRank on the handle's device; world <= 64
- *   morna_comm_info        rank, world and (when offsets != NULL: collective) offsets[world + 1]
+ *   morna_comm_info        rank, world and (when offsets != NULL: collective, always exchanges) offsets[world + 1].  The
+ *                          sharded calls exchange the row counts themselves at their first use and whenever THIS handle's
+ *                          row count has changed; ranks that resize must do so together (or call this on every rank)
  *   *_by_item_sharded      every rank contributes stored rows of ITS shard as queries (local ids); the answers come back
  *                          for all ranks' queries, rank 0's first.  n_each[world] = every rank's query count, or NULL
  *                          (then the counts are exchanged first).  Query rows travel HBM -> xGMI -> HBM.

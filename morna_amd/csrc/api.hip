@@ -696,8 +696,8 @@ static int load_impl(morna_index *h, const char *path, FILE *f)
     std::vector<float> buf;
     h->host_rows.clear(); h->host_n = 0; h->host_dirty = false; h->built = false;
     h->half_valid = false;
+    if (h->n_items != hd.n_items) h->comm_sizes_valid = false;
     h->n_items = hd.n_items;
-    h->comm_sizes_valid = false;
     MORNA_TRY(h->X.alloc((size_t)std::max<int64_t>(hd.n_items, 1) * h->dpad));
     (void)hipMemset(h->X.p, 0, (size_t)std::max<int64_t>(hd.n_items, 1) * h->dpad * 4);
     if (hd.n_items > 0) {

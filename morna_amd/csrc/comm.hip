@@ -75,8 +75,11 @@ int need_comm(morna_index *h)
     return MORNA_OK;
 }
 
-// every rank's row count -> the global id offsets.  One 8-byte all-gather and one host wait, repeated only after the
-// rows of the handle changed (every rank builds / loads in step, so every rank comes here in step).
+// every rank's row count -> the global id offsets.  One 8-byte all-gather and one host wait: at the first sharded call
+// behind morna_comm_init and again whenever THIS handle's row count has changed since (a rebuild of the same number of rows
+// -- bench.py's steps -- exchanges nothing and waits for nothing).  The exchange is a collective, so the ranks must change
+// their row counts together; a caller that resizes some shards only calls morna_comm_info(.., offsets) on every rank,
+// which always exchanges.
 int sync_sizes(morna_index *h)
 {
     MORNA_TRY(upload_host_rows(h));
@@ -391,6 +394,7 @@ int morna_comm_info(morna_index *h, int32_t *rank, int32_t *world, int64_t *offs
     if (rank) *rank = h->comm_rank;
     if (world) *world = h->comm_world;
     if (offsets) {
+        h->comm_sizes_valid = false;   // asked for: exchanged (every rank calls this together)
         MORNA_TRY(sync_sizes(h));
         memcpy(offsets, h->comm_offsets.data(), (size_t)(h->comm_world + 1) * 8);
     }

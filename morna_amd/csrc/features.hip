@@ -804,8 +804,8 @@ int upload_host_rows(morna_index *h)
         HIP_TRY(hipMemcpy2DAsync(h->X.p, (size_t)h->dpad * sizeof(float), h->host_rows.data(),
                                  (size_t)h->dim * sizeof(float), (size_t)h->dim * sizeof(float), (size_t)n,
                                  hipMemcpyHostToDevice, h->stream));
+    if (h->n_items != n) h->comm_sizes_valid = false;   // (comm.hip: the shard offsets follow the row count)
     h->n_items = n;
-    h->comm_sizes_valid = false;
     h->host_dirty = false;
     h->built = false;
     MORNA_TRY(compute_norms(h));
@@ -973,8 +973,8 @@ int build_features(morna_index *h, int64_t n_items)
             hipLaunchKernelGGL(transpose_convert_kernel, tg, dim3(256), 0, h->stream, colacc.p, n_items, D, h->dpad, item_of, h->X.p);
         }
         HIP_TRY(hipGetLastError());
+        if (h->n_items != n_items) h->comm_sizes_valid = false;   // (comm.hip: the shard offsets follow the row count)
         h->n_items = n_items;
-        h->comm_sizes_valid = false;
         h->host_n = 0;
         h->host_rows.clear();
         h->host_dirty = false;
