@@ -561,7 +561,12 @@ def main():
                         / max(tm["launches"] // max(n_steps, 1), 1)
                     g["traffic_source"] = tj_name + " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
             if g["frac"] > 1.0:
-                raise SystemExit("bench.py: roofline fraction %.2f > 1 for %s -- the bytes or the peak are wrong" % (g["frac"], name))
+                # algorithmic bytes over time can only pass the HBM peak when the bytes never came from HBM: a matrix that
+                # fits the 256-MB Infinity Cache (rehearsal sizes).  At the benchmark's own sizes it means wrong accounting.
+                if 4.0 * dpad_of(D) * n_items >= 512e6 or g["bound"] != "hbm":
+                    raise SystemExit("bench.py: roofline fraction %.2f > 1 for %s -- the bytes or the peak are wrong" % (g["frac"], name))
+                g["served_from_cache"] = "the %d x %d matrix (%.0f MB) fits the Infinity Cache: this is not an HBM rate" % (
+                    n_items, D, 4e-6 * dpad_of(D) * n_items)
             return g
         groups = {n: group(n, timers, n_bd) for n in GROUPS + ("tm_strip", "tm_wave")}   # the two two_means kernels beside their group
         groups = {n: g for n, g in groups.items() if g}
