@@ -222,16 +222,10 @@ def sharded_overhead(args, index, n_items, items, k, step):
     sk.bind(("127.0.0.1", 0))
     port = sk.getsockname()[1]
     sk.close()
-    # RCCL prints a version banner on stdout when it starts: this run's stdout is ONE JSON line, so the banner goes to stderr
-    sys.stdout.flush()
-    saved_stdout = os.dup(1)
-    os.dup2(2, 1)
     try:
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
                                 device_id=torch.device("cuda", torch.cuda.current_device()))
     except Exception as e:      # no RCCL in this environment: the key says so
-        os.dup2(saved_stdout, 1)
-        os.close(saved_stdout)
         return {"error": str(e)[:200]}
     try:
         ss = ShardedSearch(index, 0, 1, n_items)
@@ -254,9 +248,6 @@ def sharded_overhead(args, index, n_items, items, k, step):
                         "top-k packed in HBM, ncclAllGather, merge kernel; one host wait"}
     finally:
         dist.destroy_process_group()
-        sys.stdout.flush()
-        os.dup2(saved_stdout, 1)
-        os.close(saved_stdout)
 
 
 def cpu_baseline(args, data, prep, items):
@@ -311,6 +302,11 @@ def cpu_baseline(args, data, prep, items):
 
 def main():
     args = parse()
+    # stdout carries ONE line, the JSON: RCCL and gloo print banners from C++ ("RCCL version ...", "[Gloo] Rank 0 is
+    # connected ..."), so for the whole run file descriptor 1 points at stderr and the line is written to the real stdout
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -633,7 +629,8 @@ def main():
             out["cpu_baseline_mt"] = getattr(cpu_baseline, "mt", None)   # extra: the port on all host cores
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
         if sharded is not None:
