@@ -1,5 +1,7 @@
 """BASELINE.json's configurations, each exactly as stated, under -m gpu.
 
+  configs[1]  synthetic intropolis 10k samples x 3000 features, 200 trees, k = 20: feature matrix bit-exact, forest, queries,
+              exact search.
   configs[2]  synthetic intropolis 50k samples x 3000 features, 200 trees, 1000 by-item queries, k = 20,
               search_k = 100 -- built as bench.py builds it: feature matrix bit-exact against the oracle; the first
               trees of the forest node for node against oracle mode 1 (a tree's Kiss32 streams depend on its own
@@ -189,6 +191,50 @@ def test_c3_eight_trees_bit_exact_vs_oracle_mode1(c3, capi):
             m = int(cnt[qi])
             assert ids[qi, :m].tolist() == rid, (it, sk)
             assert d[qi, :m].tobytes() == np.array(rd, np.float32).tobytes(), (it, sk)
+
+
+def test_c2_10k_samples_as_stated(capi):
+    """configs[1] as stated: synthetic intropolis 10k samples x 3000 features, 200 trees, k = 20 on one GPU -- the feature leg
+    (bit-exact against the oracle), the forest (invariants over all 200 trees; the first 4 trees node for node against oracle
+    mode 1), 1000 by-item queries at morna's defaults (distances = fp64 angular distance of the returned ids, recall vs the
+    exact search), and the exact search against the oracle."""
+    from morna_amd.annoy import AnnoyIndex
+    from morna_amd.index import prepare_csr
+    from morna_amd.synth import query_items, synthetic_intropolis
+    data = synthetic_intropolis(10_000, J=70_000)
+    prep = prepare_csr(data["keys"], data["row_ptr"], data["samples"], data["cov"], data["sample_count"], 100)
+    N = prep["n_items"]
+    assert N == 10_000
+    a = AnnoyIndex(D3)
+    a.stage_junctions(prep["key_bytes"], prep["key_off"], prep["row_ptr"], prep["ids"], prep["cov"], prep["idf"])
+    a.stage_item_order(prep["ext_ids"])
+    a.build_features(N)
+    X = a.get_items()
+    buf, off = capi.pack_keys(data["keys"])
+    ref = capi.index_features(buf, off, data["row_ptr"], data["samples"], data["cov"], data["sample_count"], 100, D3, max_items=N)
+    assert X.tobytes() == ref["X"].tobytes()
+    a.build(T3, seed=0)
+    st = _check_forest(a, N, T3, D3 + 2)
+    assert st["max_depth"] >= 2                       # ceil(log2(10000 / 3002)) = 2
+    o = capi.AnnoyOracle(D3, mode=1)
+    o.set_items(X)
+    o.build(4)
+    f = a.get_forest()
+    hp_of = {int(n): i for i, n in enumerate(f["hp_node"])}
+    roots = o.roots()
+    assert sum(_compare_tree(f, hp_of, o, t, roots[t]) for t in range(4)) == o.n_nodes()
+    items = query_items(N, Q3)
+    ids, d, cnt = a.get_nns_by_item_batch(items, K3, SEARCH_K)
+    assert (cnt == K3).all() and (ids[:, 0] == items).all()
+    for qi in range(0, Q3, 10):
+        assert np.allclose(d[qi], _true_ang(X, X[int(items[qi])], ids[qi]), atol=2e-5)
+    eids, ed, ecnt = a.exact_search_by_item_batch(items, K3)
+    assert (ecnt == K3).all()
+    recall = np.mean([len(set(ids[i].tolist()) & set(eids[i].tolist())) / float(K3) for i in range(Q3)])
+    assert recall >= 0.95, recall
+    for qi in range(0, Q3, 50):
+        rid, rd = capi.exact_search(X, X[int(items[qi])].astype(np.float64), K3)
+        assert eids[qi].tolist() == rid.tolist() and ed[qi].tobytes() == rd.tobytes()
 
 
 def _build_shard_from_prep(prep, sample_count, rank, world, n_trees, device=0):
