@@ -196,14 +196,15 @@ def query_sweep(args, index, items, k, st):
         if nq == 1:
             floor_b = cand * dp * 2 + dots * dp * 4
             moved_b = cand * dp * 4 + dots * dp * 4        # the spread form reads the candidates' fp32 rows (no fp16 filter stage)
-            pops = rows - cand - 1 - st["n_trees"]         # hyperplane dots below the roots: one dependent pop each
             e["byte_floor"] = {"bytes": floor_b, "us_at_hbm_peak": floor_b / (HBM_PEAK_GBS * 1e3),
                                "bytes_moved": moved_b, "kernel_us": 1e3 * tq["ms"],
                                "kernel_over_floor": 1e3 * tq["ms"] / max(floor_b / (HBM_PEAK_GBS * 1e3), 1e-9),
                                "what": "%.0f candidates x %d B (fp16 rows) + %d hyperplanes x %d B" % (cand, dp * 2, dots, dp * 4),
-                               "latency_chain": "%.0f dependent pops below the roots (queue maximum -> node record + hyperplane -> "
-                                                "canonical dot -> push), then one leaf: the chain, not the bytes, is what a "
-                                                "lone query waits for" % pops}
+                               "latency_chain": "below the roots the descent pops nodes ONE AFTER THE OTHER (queue maximum -> node "
+                                                "record + hyperplane -> canonical dot -> push; annoy's queue hops between trees, "
+                                                "so more pops than the depth: 14 + one leaf at this query by the kernel's cycle "
+                                                "stamps, DESIGN.md section 5): that chain, not the bytes, is what a lone query waits for; "
+                                                "`what` estimates hyperplanes as trees + depth"}
         out["nq_%d" % nq] = e
     return out
 
