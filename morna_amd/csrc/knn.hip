@@ -270,17 +270,23 @@ __global__ __launch_bounds__(Q_THREADS) void query_roots_kernel(QueryParams P)
 }
 
 #define PQ_LDS 1024   // queue entries kept in LDS by the one-wave descent; entries beyond stay in the global array
-// One wave per query.  A pop is a chain -- the entry with the largest bound, its node record, its hyperplane, one dot -- and
-// the descent is a chain of pops (five or six at morna's defaults), so what counts is the length of one: the queue sits in
-// LDS with the hyperplane slot of every entry beside it (the slot of a node is looked up when the node is PUSHED, under the
-// hyperplane fetch of its parent), so that the record and the hyperplane of a popped node are requested together: one
-// round trip to memory per pop instead of two; the maximum is taken with cross-lane moves; a leaf's ids are fetched eight
-// loads at a time, and the first leaf -- whose ids are distinct, a tree lists an item once -- is copied without touching the
-// bitmap when it ends the search (the case of search_k = 100 with leaves of ~K ids).
-// NV: float4 per lane of a row (dpad / 256) when the query fits the wave's registers -- it is then loaded ONCE and every
-// hyperplane is requested whole, all its 1-KiB pieces in flight together (a lone wave that keeps four loads in flight moves
-// ~13 GB/s: the 24 KB of a dot by wave_dot() took 2 us, most of a pop); 0: any row length, through wave_dot().  Same fmaf
-// chains either way.
+// One wave per query.  A pop is a chain -- the entry with the largest bound, its node's record and hyperplane, one dot, two
+// pushes -- and the descent is a chain of pops (C3 at morna's defaults: 14 internal nodes and one leaf; annoy's queue hops
+// between the trees), so what counts is the length of ONE pop.  A lone wave issues an instruction every ~4.3 cycles and a
+// trip to HBM takes ~1000, so:
+//   * the queue sits in LDS, bounds and nodes as two 32-bit arrays: the maximum is taken on the 32-bit bounds (8 x v_max +
+//     a 6-step cross-lane maximum); only when two entries share the largest bound do the 64-bit keys decide (annoy's
+//     (bound, node) order), by the slow scan;
+//   * the record and the hyperplane of a popped node are requested together (the hyperplane slot of every entry sits beside
+//     it: looked up when the node is PUSHED, under its parent's hyperplane fetch): one round trip per pop; the query stays in
+//     registers (NV > 0) and a hyperplane's 1-KiB pieces are all requested at once;
+//   * (tried: the margins, records and child slots of the roots' children -- most of the pops -- made ahead by the root-margin
+//     kernel, so that those pops touch LDS only: the descent 22 -> 18 us, the root kernel 4.9 -> 7.3 us with three times the
+//     dots, the launch no shorter; dropped)
+//   * the first leaf, when it ends the search (search_k = 100, leaves of ~K ids), is not copied: its slice of the tree's
+//     permutation IS the candidate list (distinct ids: a tree lists an item once).
+// NV: float4 per lane of a row (dpad / 256) when the query fits the wave's registers; 0: any row length, through
+// wave_dot().  Same fmaf chains either way.
 template <int NV>
 __device__ inline float wave_dot_held(const float4 *__restrict__ row, const float4 (&qr)[NV > 0 ? NV : 1], int lane)
 {
@@ -293,12 +299,34 @@ __device__ inline float wave_dot_held(const float4 *__restrict__ row, const floa
     return acc4_finish(s);
 }
 
+// the wave's maximum of a 32-bit value (0 = nothing), every lane gets it: cross-lane moves only
+__device__ inline uint32_t wave_max_u32_fast(uint32_t v)
+{
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    v = v > r[1] ? v : r[1];
+    r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = v > r[1] ? v : r[1];
+    uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x108, 0xf, 0xf, true);
+    v = v > o ? v : o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0xf, true);
+    v = v > o ? v : o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x102, 0xf, 0xf, true);
+    v = v > o ? v : o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true);
+    v = v > o ? v : o;
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 template <bool BM_LDS, int NV>
 __global__ __launch_bounds__(WAVE) void query_descend_kernel(QueryParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint64_t s_pq[PQ_LDS];
-    __shared__ int32_t s_slot[PQ_LDS];   // hyperplane slot of the entry's node, -1: a leaf
+    // a queue entry = (bound as an orderable 32-bit word, node); an empty slot has bound word 0 (no real bound maps to 0:
+    // f32_orderable() of a non-NaN float is >= 0x00800000 ... and the words of the negative floats are the complements)
+    __shared__ uint32_t s_bound[PQ_LDS];
+    __shared__ int32_t s_node[PQ_LDS];
+    __shared__ int32_t s_slot[PQ_LDS];    // hyperplane slot of the entry's node, -1: a leaf
     __shared__ int s_ncand;
     const int lane = threadIdx.x;
     const int64_t qi = blockIdx.x;
@@ -324,19 +352,29 @@ __global__ __launch_bounds__(WAVE) void query_descend_kernel(QueryParams P)
     {
         // the queue as the root margins left it, and the hyperplane slot of every entry's node: all the loads of a phase in
         // flight together (written as one loop, every iteration waited for its two dependent round trips)
-        uint64_t k16[PQ_LDS / WAVE];
-        int32_t s16[PQ_LDS / WAVE];
+        auto init = [&](auto NU) {
+            constexpr int nu = decltype(NU)::value;
+            uint64_t k16[nu];
+            int32_t s16[nu];
 #pragma unroll
-        for (int u = 0; u < PQ_LDS / WAVE; u++) {
-            const int i = lane + WAVE * u;
-            k16[u] = i < hn ? (roots_split ? gpq[i] : pq_key(INFINITY, i)) : 0;
-        }
+            for (int u = 0; u < nu; u++) {
+                const int i = lane + WAVE * u;
+                k16[u] = i < hn ? (roots_split ? gpq[i] : pq_key(INFINITY, i)) : 0;
+            }
 #pragma unroll
-        for (int u = 0; u < PQ_LDS / WAVE; u++) s16[u] = lane + WAVE * u < hn ? P.node_hp[(int32_t)(uint32_t)k16[u]] : -1;
+            for (int u = 0; u < nu; u++) s16[u] = lane + WAVE * u < hn ? P.node_hp[(int32_t)(uint32_t)k16[u]] : -1;
 #pragma unroll
-        for (int u = 0; u < PQ_LDS / WAVE; u++) {
-            s_pq[lane + WAVE * u] = k16[u];       // (0 beyond hn: an empty slot)
-            s_slot[lane + WAVE * u] = s16[u];
+            for (int u = 0; u < nu; u++) {
+                s_bound[lane + WAVE * u] = (uint32_t)(k16[u] >> 32);   // (0 beyond hn: an empty slot)
+                s_node[lane + WAVE * u] = (int32_t)(uint32_t)k16[u];
+                s_slot[lane + WAVE * u] = s16[u];
+            }
+        };
+        if (hn <= 8 * WAVE) {
+            init(std::integral_constant<int, 8>());
+            for (int i = 8 * WAVE + lane; i < PQ_LDS; i += WAVE) s_bound[i] = 0;   // slots the pushes will fill
+        } else {
+            init(std::integral_constant<int, PQ_LDS / WAVE>());
         }
     }
     if (!roots_split)
@@ -349,46 +387,69 @@ __global__ __launch_bounds__(WAVE) void query_descend_kernel(QueryParams P)
     const int64_t search_k = P.search_k;
     TP();
     while (nn < search_k) {
-        uint64_t best = 0;
-        int bestpos = -1;
+        // ---- the entry with the largest (bound, node)
+        int pos = -1;
+        uint32_t top_b = 0;
         {
-            // (slots beyond hn hold 0; a lone wave issues an instruction every ~4 cycles, so the scan is its instruction count:
-            // eight entries per lane while the queue is that short -- 200 trees give 400 entries + 2 per pop)
-            auto scan = [&](auto NU) {
+            const int hl = hn < PQ_LDS ? hn : PQ_LDS;
+            auto pick = [&](auto NU) {
                 constexpr int nu = decltype(NU)::value;
-                uint64_t kk[nu];
+                uint32_t bb[nu], mb = 0;
 #pragma unroll
-                for (int u = 0; u < nu; u++) kk[u] = s_pq[lane + WAVE * u];
+                for (int u = 0; u < nu; u++) bb[u] = s_bound[lane + WAVE * u];   // (slots beyond hn hold 0)
+#pragma unroll
+                for (int u = 0; u < nu; u++) mb = bb[u] > mb ? bb[u] : mb;
+                for (int i = PQ_LDS + lane; i < hn; i += WAVE) {   // (entries beyond the LDS arrays: global)
+                    const uint32_t b = (uint32_t)(gpq[i] >> 32);
+                    mb = b > mb ? b : mb;
+                }
+                top_b = wave_max_u32_fast(mb);
+                if (top_b == 0) return;               // queue empty
+                // who holds it?  One entry as a rule; several (equal bounds, e.g. both children behind a zero margin): annoy's
+                // pair order pops the larger node id first
+                int cnt = 0, mypos = -1;
 #pragma unroll
                 for (int u = 0; u < nu; u++)
-                    if (kk[u] > best) { best = kk[u]; bestpos = lane + WAVE * u; }
+                    if (bb[u] == top_b) { cnt++; mypos = lane + WAVE * u; }
+                const unsigned long long holders = __ballot(cnt > 0);
+                if (hn <= PQ_LDS && __popcll(holders) == 1 && __builtin_amdgcn_readlane(cnt, __ffsll((long long)holders) - 1) == 1) {
+                    pos = __builtin_amdgcn_readlane(mypos, __ffsll((long long)holders) - 1);
+                    return;
+                }
+                int32_t mynode = -1;                  // the slow way: the largest node among the holders
+                mypos = -1;
+                for (int i = lane; i < hn; i += WAVE) {
+                    const bool il = i < PQ_LDS;
+                    const uint32_t b = il ? s_bound[i] : (uint32_t)(gpq[i] >> 32);
+                    if (b == top_b) {
+                        const int32_t nd = il ? s_node[i] : (int32_t)(uint32_t)gpq[i];
+                        if (nd > mynode) { mynode = nd; mypos = i; }
+                    }
+                }
+                const uint32_t best_node = wave_max_u32_fast(mypos >= 0 ? (uint32_t)mynode + 1u : 0u) - 1u;   // node ids are >= 0
+                const unsigned long long w2 = __ballot(mypos >= 0 && (uint32_t)mynode == best_node);
+                pos = __builtin_amdgcn_readlane(mypos, __ffsll((long long)w2) - 1);
             };
-            if (hn <= 8 * WAVE) scan(std::integral_constant<int, 8>());
-            else scan(std::integral_constant<int, PQ_LDS / WAVE>());
+            if (hl <= 8 * WAVE) pick(std::integral_constant<int, 8>());
+            else pick(std::integral_constant<int, PQ_LDS / WAVE>());
+            if (top_b == 0) break;
         }
-        for (int i = PQ_LDS + lane; i < hn; i += WAVE) {
-            const uint64_t kk = gpq[i];
-            if (kk > best) { best = kk; bestpos = i; }
-        }
-        const uint64_t top = wave_max_u64_fast(best);
         TP();
-        if (top == 0) break;                       // queue empty
-        const unsigned long long owners = __ballot(best == top && bestpos >= 0);   // exactly one lane (keys are distinct)
-        const int pos = __builtin_amdgcn_readlane(bestpos, __ffsll((long long)owners) - 1);
+        const bool in_lds = pos < PQ_LDS;
+        const int32_t node = in_lds ? s_node[pos] : (int32_t)(uint32_t)gpq[pos];
+        const float d = f32_from_orderable(top_b);
         if (lane == 0) {
-            if (pos < PQ_LDS) s_pq[pos] = 0;
+            if (in_lds) s_bound[pos] = 0;
             else gpq[pos] = 0;
         }
-        const int32_t node = (int32_t)(uint32_t)top;
-        const float d = f32_from_orderable((uint32_t)(top >> 32));
-        const int32_t slot = pos < PQ_LDS ? s_slot[pos] : P.node_hp[node];
-        const int4 rec = *(const int4 *)(P.node_rec + 4 * (int64_t)node);   // child0, child1, start, count
+        const int32_t slot = in_lds ? s_slot[pos] : P.node_hp[node];
         if (slot < 0) {
             // leaf: nns.insert(all ids); duplicates across trees are dropped by the bitmap
+            const int4 rec = *(const int4 *)(P.node_rec + 4 * (int64_t)node);
             const int32_t *src_ids = P.perm + (int64_t)P.node_tree[node] * P.n_items + rec.z;
             const int count = rec.w;
             if (n_leaves == 0 && nn + count >= search_k) {
-                // the first leaf ends the search: its ids ARE the candidates (distinct: a tree lists an item once) -- not copied
+                // the first leaf ends the search: its ids ARE the candidates -- not copied
                 if (lane == 0) {
                     s_ncand = count;
                     cand_off = (int64_t)P.node_tree[node] * P.n_items + rec.z;
@@ -422,6 +483,7 @@ __global__ __launch_bounds__(WAVE) void query_descend_kernel(QueryParams P)
             nn += count;
             n_leaves++;
         } else {
+            const int4 rec = *(const int4 *)(P.node_rec + 4 * (int64_t)node);
             // the children's slots are wanted when they are popped, not now: requested here, under the hyperplane fetch
             const int32_t slot_c = lane < 2 ? P.node_hp[lane == 0 ? rec.y : rec.x] : 0;
             const float4 *hrow = (const float4 *)(P.hp + (int64_t)slot * P.dpad);
@@ -429,7 +491,8 @@ __global__ __launch_bounds__(WAVE) void query_descend_kernel(QueryParams P)
             if (lane < 2) {
                 const uint64_t key = lane == 0 ? pq_key(d < m ? d : m, rec.y) : pq_key(d < -m ? d : -m, rec.x);
                 if (hn + lane < PQ_LDS) {
-                    s_pq[hn + lane] = key;
+                    s_bound[hn + lane] = (uint32_t)(key >> 32);
+                    s_node[hn + lane] = (int32_t)(uint32_t)key;
                     s_slot[hn + lane] = slot_c;
                 } else {
                     gpq[hn + lane] = key;
