@@ -541,3 +541,35 @@ def test_feature_build_ignores_ids_past_n_items():
     assert out[0].tobytes() == out[1].tobytes() == out[2].tobytes()
     keep = np.array(ids) < n_items
     assert (out[0] != 0).any() and keep.sum() < len(ids)
+
+
+def test_exact_search_large_shard_selection_edges(capi):
+    """Shards of more than 8192 rows take the two-pass selection (exact_select2_kernel).  Its edges: a tie group far larger than
+    the candidate room (5000 identical rows: the first pass collects them all, the host makes room and repeats), k above the
+    256 the two-pass form handles (falls back to the k-round form), k larger than a thread's share -- each against the
+    oracle's bisect_left order (equal distance: higher id first) and against the k-round selection (MORNA_EXACT_SELECT2=0)."""
+    import os
+    from morna_amd.annoy import AnnoyIndex
+    rng = np.random.default_rng(12)
+    N, D = 9000, 40
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    dup = rng.choice(N, 5000, replace=False)
+    X[dup] = X[dup[0]]                                   # 5000 copies of one row
+    X[dup[:50]] *= np.float32(2.0)                       # some of them scaled by a power of two: still distance 0
+    a = AnnoyIndex(D)
+    a.add_items(X)
+    items = np.array([int(dup[0]), int(dup[77]), 3, 4], np.int32)
+    for k in (10, 300, 6000):
+        ids, d, cnt = a.exact_search_by_item_batch(items, k)
+        os.environ["MORNA_EXACT_SELECT2"] = "0"
+        try:
+            ids0, d0, cnt0 = a.exact_search_by_item_batch(items, k)
+        finally:
+            del os.environ["MORNA_EXACT_SELECT2"]
+        assert ids.tolist() == ids0.tolist() and d.tobytes() == d0.tobytes() and cnt.tolist() == cnt0.tolist(), k
+        for qi, it in enumerate(items):
+            rid, rd = capi.exact_search(X, X[int(it)].astype(np.float64), k)
+            assert ids[qi, :len(rid)].astype(np.int64).tolist() == rid.tolist(), (k, qi)
+            assert d[qi, :len(rid)].tobytes() == rd.tobytes(), (k, qi)
+    ids, d, cnt = a.exact_search_by_item_batch(items[:1], 10)
+    assert d[0].tolist() == [0.0] * 10 and ids[0].tolist() == sorted(dup.tolist(), reverse=True)[:10]
