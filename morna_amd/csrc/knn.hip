@@ -45,7 +45,8 @@ struct QueryParams {
     // workspace, one slice per query
     uint64_t *pq;              // [nq][n_nodes]
     int32_t *cand;             // [nq][cap]
-    int64_t *cand_off;         // [nq] spread form: >= 0: the candidates are perm[cand_off .. + ncand) (one leaf, not copied); -1: cand[]
+    int64_t *cand_off;         // [nq] one-wave descent: >= 0: the candidates are perm[cand_off .. + ncand) (one leaf, not copied); -1: cand[]
+    int32_t zero_copy;         // the consumer reads the candidates through cand_off (query_cand_dots_kernel); 0: always copied to cand[]
     uint64_t *keys;            // [nq][cap]
     float *low;                // [nq][cap] lower bound of a candidate's distance (filter modes)
     int32_t *ncand;            // [nq] unique candidates found by the traversal (may exceed cap)
@@ -140,6 +141,21 @@ __device__ inline uint64_t block_kth_smallest(const uint64_t *keys, int n, int k
         kth = block_min_u64(best, s_red, tid);
     }
     return kth;
+}
+
+// A canonical dot with the query held in the wave's registers: the whole row is requested at once, all its 1-KiB pieces in
+// flight together (through wave_dot(), four loads in flight, a lone wave moves a 12-KB hyperplane in ~2 us).  NV = float4
+// per lane of a row (dpad / 256).  The same fmaf chains as wave_dot().
+template <int NV>
+__device__ inline float wave_dot_held(const float4 *__restrict__ row, const float4 (&qr)[NV > 0 ? NV : 1], int lane)
+{
+    float4 x[NV > 0 ? NV : 1];
+#pragma unroll
+    for (int k = 0; k < NV; k++) x[k] = row[lane + WAVE * k];
+    Acc4 s = acc4_zero();
+#pragma unroll
+    for (int k = 0; k < NV; k++) fma4(s, x[k], qr[k]);
+    return acc4_finish(s);
 }
 
 // ---- traversal: annoy's _get_all_nns up to the candidate set (oracle/annoy_oracle.c:453-504) -------------------
@@ -269,6 +285,62 @@ __global__ __launch_bounds__(Q_THREADS) void query_roots_kernel(QueryParams P)
     }
 }
 
+// Root margins of a BATCH: a workgroup takes QR_Q queries (their rows in LDS) and a share of the trees; a wave fetches a
+// root's hyperplane ONCE into registers, all its pieces in flight, and takes its canonical dot with each of the QR_Q queries
+// (one workgroup per query fetched every hyperplane once per query: 200 k dots x 12 KB out of L2 for 1000 queries, and a
+// wave's 50 dots one after the other, 100 us of a workgroup's life).  The descent then runs as in the spread form, one wave
+// per query (query_descend_kernel).  Same fmaf chains as wave_dot(): a product's factors commute.
+#ifndef QR_Q
+#define QR_Q 4         // (8 queries and / or 512 threads, 2 queries: the same time within 2 % at 50k and at 6250 rows)
+#endif
+#ifndef QR_THREADS
+#define QR_THREADS 256
+#endif
+#define QR_WAVES (QR_THREADS / WAVE)
+#define QR_TREES 48   // trees per workgroup
+template <int NV>
+__global__ __launch_bounds__(QR_THREADS) void query_roots_batch_kernel(QueryParams P, int32_t nq)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *qs = (float4 *)smem;   // [QR_Q][nvec]
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int nvec = P.dpad / 4;
+    const int64_t q0 = (int64_t)blockIdx.x * QR_Q;
+    const int nqs = (int)(nq - q0 < QR_Q ? nq - q0 : QR_Q);
+    for (int i = tid; i < QR_Q * nvec; i += QR_THREADS) {
+        const int qq = i / nvec, v = i - qq * nvec;
+        qs[i] = qq < nqs ? query_row(P, q0 + qq)[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    if (blockIdx.y == 0)   // the queries' own canonical norms, once
+        for (int qq = w; qq < nqs; qq += QR_WAVES) {
+            const float pp = wave_dot(qs + qq * nvec, qs + qq * nvec, nvec, lane);
+            if (lane == 0) P.qpp[q0 + qq] = pp;
+        }
+    const int t_end = (int)(blockIdx.y + 1) * QR_TREES < P.n_trees ? (int)(blockIdx.y + 1) * QR_TREES : P.n_trees;
+    for (int t = (int)blockIdx.y * QR_TREES + w; t < t_end; t += QR_WAVES) {
+        const float4 *hrow = (const float4 *)(P.hp + (int64_t)P.node_hp[t] * P.dpad);
+        const int32_t c0 = P.node_rec[4 * t + 0], c1 = P.node_rec[4 * t + 1];
+        float4 hr[NV];
+#pragma unroll
+        for (int k = 0; k < NV; k++) hr[k] = hrow[lane + WAVE * k];
+#pragma unroll
+        for (int qq = 0; qq < QR_Q; qq++) {
+            if (qq < nqs) {   // uniform
+                Acc4 s4 = acc4_zero();
+#pragma unroll
+                for (int k = 0; k < NV; k++) fma4(s4, hr[k], qs[qq * nvec + lane + WAVE * k]);
+                const float m = acc4_finish(s4);
+                if (lane == 0) {
+                    uint64_t *pq = P.pq + (q0 + qq) * P.n_nodes;
+                    pq[2 * t] = pq_key(m, c1);        // min(+inf, margin), children[1]
+                    pq[2 * t + 1] = pq_key(-m, c0);   // min(+inf, -margin), children[0]
+                }
+            }
+        }
+    }
+}
+
 #define PQ_LDS 1024   // queue entries kept in LDS by the one-wave descent; entries beyond stay in the global array
 // One wave per query.  A pop is a chain -- the entry with the largest bound, its node's record and hyperplane, one dot, two
 // pushes -- and the descent is a chain of pops (C3 at morna's defaults: 14 internal nodes and one leaf; annoy's queue hops
@@ -287,18 +359,6 @@ __global__ __launch_bounds__(Q_THREADS) void query_roots_kernel(QueryParams P)
 //     permutation IS the candidate list (distinct ids: a tree lists an item once).
 // NV: float4 per lane of a row (dpad / 256) when the query fits the wave's registers; 0: any row length, through
 // wave_dot().  Same fmaf chains either way.
-template <int NV>
-__device__ inline float wave_dot_held(const float4 *__restrict__ row, const float4 (&qr)[NV > 0 ? NV : 1], int lane)
-{
-    float4 x[NV > 0 ? NV : 1];
-#pragma unroll
-    for (int k = 0; k < NV; k++) x[k] = row[lane + WAVE * k];
-    Acc4 s = acc4_zero();
-#pragma unroll
-    for (int k = 0; k < NV; k++) fma4(s, x[k], qr[k]);
-    return acc4_finish(s);
-}
-
 // the wave's maximum of a 32-bit value (0 = nothing), every lane gets it: cross-lane moves only
 __device__ inline uint32_t wave_max_u32_fast(uint32_t v)
 {
@@ -448,7 +508,7 @@ __global__ __launch_bounds__(WAVE) void query_descend_kernel(QueryParams P)
             const int4 rec = *(const int4 *)(P.node_rec + 4 * (int64_t)node);
             const int32_t *src_ids = P.perm + (int64_t)P.node_tree[node] * P.n_items + rec.z;
             const int count = rec.w;
-            if (n_leaves == 0 && nn + count >= search_k) {
+            if (P.zero_copy && n_leaves == 0 && nn + count >= search_k) {
                 // the first leaf ends the search: its ids ARE the candidates -- not copied
                 if (lane == 0) {
                     s_ncand = count;
@@ -945,7 +1005,7 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
                  s_bm = bm_lds ? 0 : align_up((size_t)batch * bm_words * 4, 256),
                  s_ids = align_up((size_t)batch * k * 4, 256),
                  s_scores = may_dense ? align_up((size_t)batch * N * 4, 256) : 0;
-    MORNA_TRY(h->ws.alloc(s_pq + s_keys + s_q + s_q16 + 7 * s_qf + 2 * s_cand + s_bm + 2 * s_ids + s_scores));
+    MORNA_TRY(h->ws.alloc(s_pq + s_keys + s_q + s_q16 + 9 * s_qf + 2 * s_cand + s_bm + 2 * s_ids + s_scores));
     MORNA_TRY(h->d_stat.alloc(4));
     if (use_filter) MORNA_TRY(split_mm_prepare_rows(h, h->stream));
 
@@ -968,6 +1028,8 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
         float *q_scale = (float *)p; p += s_qf;
         P.ncand = (int32_t *)p; p += s_qf;
         int32_t *d_items = (int32_t *)p; p += s_qf;   // (part of the workspace: a hipMalloc / hipFree per call costs tens of microseconds)
+        P.cand_off = (int64_t *)p; p += 2 * s_qf;
+        P.zero_copy = spread ? 1 : 0;
         P.cand = (int32_t *)p; p += s_cand;
         P.low = (float *)p; p += s_cand;
         P.bm_global = (uint32_t *)p; p += s_bm;
@@ -977,7 +1039,6 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
         P.count_out = (int32_t *)p; p += s_qf;
         float *scores = (float *)p; p += s_scores;
         P.stat = h->d_stat.p;
-        P.cand_off = (int64_t *)P.low;   // (the spread form has no lower bounds: the array's first 8 bytes per query)
         P.X16 = nullptr; P.xscale = nullptr; P.xn16 = P.xe16 = nullptr; P.delta = 0.f;
         P.scores = nullptr; P.qscale = P.qn16 = P.qe16 = nullptr; P.eacc = P.eacc_big = 0.f; P.big_rows = 0;
         if (use_filter) {
@@ -1033,6 +1094,36 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
             HIP_TRY(hipMemcpyAsync(d_items, items_host + q0, (size_t)nb * 4, hipMemcpyHostToDevice, h->stream));
             P.items = d_items;
         }
+        // the best-first descent, one wave per query (query_descend_kernel), on stream st
+        auto launch_descend = [&](hipStream_t st) -> int {
+            const size_t bl = bm_lds ? (size_t)bm_words * 4 : 0;
+#define DESCEND(NVV)                                                                                                              \
+    do {                                                                                                                          \
+        if (bm_lds) {                                                                                                             \
+            if (bl > 32 * 1024)                                                                                                   \
+                HIP_TRY(hipFuncSetAttribute((const void *)query_descend_kernel<true, NVV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                            (int)bl));                                                                            \
+            hipLaunchKernelGGL((query_descend_kernel<true, NVV>), dim3((unsigned)nb), dim3(WAVE), bl, st, P);                     \
+        } else {                                                                                                                  \
+            hipLaunchKernelGGL((query_descend_kernel<false, NVV>), dim3((unsigned)nb), dim3(WAVE), 0, st, P);                     \
+        }                                                                                                                         \
+    } while (0)
+            switch (h->dpad / 256) {   // float4 per lane of a row
+            case 1: DESCEND(1); break;
+            case 2: DESCEND(2); break;
+            case 3: DESCEND(3); break;
+            case 4: DESCEND(4); break;
+            case 6: DESCEND(6); break;
+            case 8: DESCEND(8); break;
+            case 12: DESCEND(12); break;
+            case 16: DESCEND(16); break;
+            case 24: DESCEND(24); break;
+            case 32: DESCEND(32); break;
+            default: DESCEND(0); break;
+            }
+#undef DESCEND
+            return MORNA_OK;
+        };
         // spread form, answers wanted on the host: the last kernel writes them straight into page-locked memory of the handle
         // (a copy out of HBM is another ~8 us operation on the stream for 160 bytes per query)
         const bool direct = spread && ids_out && !packed_dev;
@@ -1056,32 +1147,7 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
             ScopedTimer tm(h, MORNA_T_QUERY, 0);
             hipLaunchKernelGGL(query_roots_kernel, dim3((unsigned)((h->n_trees + Q_WAVES - 1) / Q_WAVES), (unsigned)nb), dim3(Q_THREADS), 0,
                                h->stream, P);
-            const size_t bl = bm_lds ? (size_t)bm_words * 4 : 0;
-#define DESCEND(NVV)                                                                                                              \
-    do {                                                                                                                          \
-        if (bm_lds) {                                                                                                             \
-            if (bl > 32 * 1024)                                                                                                   \
-                HIP_TRY(hipFuncSetAttribute((const void *)query_descend_kernel<true, NVV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                            (int)bl));                                                                            \
-            hipLaunchKernelGGL((query_descend_kernel<true, NVV>), dim3((unsigned)nb), dim3(WAVE), bl, h->stream, P);              \
-        } else {                                                                                                                  \
-            hipLaunchKernelGGL((query_descend_kernel<false, NVV>), dim3((unsigned)nb), dim3(WAVE), 0, h->stream, P);              \
-        }                                                                                                                         \
-    } while (0)
-            switch (h->dpad / 256) {   // float4 per lane of a row
-            case 1: DESCEND(1); break;
-            case 2: DESCEND(2); break;
-            case 3: DESCEND(3); break;
-            case 4: DESCEND(4); break;
-            case 6: DESCEND(6); break;
-            case 8: DESCEND(8); break;
-            case 12: DESCEND(12); break;
-            case 16: DESCEND(16); break;
-            case 24: DESCEND(24); break;
-            case 32: DESCEND(32); break;
-            default: DESCEND(0); break;
-            }
-#undef DESCEND
+            MORNA_TRY(launch_descend(h->stream));
 #ifdef MORNA_DESCEND_PROBE
             {
                 float probe[40];
@@ -1142,7 +1208,35 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
             // beside the contraction (matrix cores, LDS) the traversal is a latency chain on one wave per query: it
             // runs on the side stream and the refine step waits for both
             hipStream_t ts = dense ? h->stream2 : h->stream;   // (forked above, before the contraction was enqueued)
-            if (bm_lds) {
+            // Root margins by query groups (a hyperplane fetched once per QR_Q queries), then the one-wave descent of the
+            // spread form -- while the rows have a length the register forms are built for and the roots do split;
+            // otherwise (and with MORNA_QUERY_SPLIT_TRAVERSE=0) the fused kernel, one workgroup per query.
+            const int nvq = h->dpad / 256;
+            const bool nv_ok = h->dpad % 256 == 0 && (nvq == 1 || nvq == 2 || nvq == 3 || nvq == 4 || nvq == 6 || nvq == 8 || nvq == 12);
+            const bool split_traverse = nv_ok && N > h->K && (size_t)QR_Q * h->dpad * 4 <= 128 * 1024 &&
+                                        !(getenv("MORNA_QUERY_SPLIT_TRAVERSE") && atoi(getenv("MORNA_QUERY_SPLIT_TRAVERSE")) == 0);
+            if (split_traverse) {
+                const dim3 grid((unsigned)((nb + QR_Q - 1) / QR_Q), (unsigned)((h->n_trees + QR_TREES - 1) / QR_TREES));
+                const size_t ql = (size_t)QR_Q * h->dpad * 4;
+#define ROOTSB(NVV)                                                                                                      \
+    do {                                                                                                                 \
+        if (ql > 48 * 1024)                                                                                              \
+            HIP_TRY(hipFuncSetAttribute((const void *)query_roots_batch_kernel<NVV>,                                      \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ql));                           \
+        hipLaunchKernelGGL((query_roots_batch_kernel<NVV>), grid, dim3(QR_THREADS), ql, ts, P, (int32_t)nb);             \
+    } while (0)
+                switch (nvq) {
+                case 1: ROOTSB(1); break;
+                case 2: ROOTSB(2); break;
+                case 3: ROOTSB(3); break;
+                case 4: ROOTSB(4); break;
+                case 6: ROOTSB(6); break;
+                case 8: ROOTSB(8); break;
+                default: ROOTSB(12); break;
+                }
+#undef ROOTSB
+                MORNA_TRY(launch_descend(ts));
+            } else if (bm_lds) {
                 if (lds > 48 * 1024)   // query image + sample bitmap can pass the default dynamic-LDS limit
                     HIP_TRY(hipFuncSetAttribute((const void *)query_traverse_kernel<true>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -5,6 +5,7 @@ The split of a level (splitmm.hip) and the candidate filter of the approximate s
 what they can PROVE and hand everything else to the canonical fp32 arithmetic, so switching them off must change
 nothing: whole-forest and search digests are compared across MORNA_SPLIT_MM = 0 / 1, MORNA_QUERY_FILTER = 0 / 1 and
 MORNA_QUERY_DENSE = 0 / 1 (the filter dots of a whole batch as one contraction, or candidate by candidate), and across
+MORNA_QUERY_SPLIT_TRAVERSE = 0 / 1 and MORNA_QUERY_SPREAD = 0 / 1 (how a batch's, and a small batch's, traversal is dealt out),
 MORNA_SPLIT_ORDER = 0 / 1 and MORNA_SPLIT_LISTS = 0 / 1 (the order of the rows of the split contraction, and the per-tile
 task lists: both only choose which products are computed; the 256-wide case with 150 trees has levels with enough split
 nodes for the lists) -- separate processes: the switches are read once.  The rows:
@@ -101,7 +102,10 @@ def test_adversarial_rows_filters_change_nothing(tmp_path, D, N, T):
     out, open_lines = {}, []
     for name, extra in (("default", {"MORNA_DEBUG_OPEN": "1"}), ("no_mm", {"MORNA_SPLIT_MM": "0"}),
                         ("no_qf", {"MORNA_QUERY_FILTER": "0"}), ("no_dense", {"MORNA_QUERY_DENSE": "0"}),
-                        ("no_order", {"MORNA_SPLIT_ORDER": "0"}), ("no_lists", {"MORNA_SPLIT_LISTS": "0", "MORNA_SPLIT_ORDER": "0"})):
+                        ("no_order", {"MORNA_SPLIT_ORDER": "0"}), ("no_lists", {"MORNA_SPLIT_LISTS": "0", "MORNA_SPLIT_ORDER": "0"}),
+                        # round 3: the traversal of a batch as root margins by query groups + one-wave descents, or fused (one
+                        # workgroup per query); small batches dealt out over the chip, or one workgroup per query
+                        ("fused_traverse", {"MORNA_QUERY_SPLIT_TRAVERSE": "0"}), ("no_spread", {"MORNA_QUERY_SPREAD": "0"})):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -109,6 +113,7 @@ def test_adversarial_rows_filters_change_nothing(tmp_path, D, N, T):
         if name == "default":
             open_lines = [ln for ln in r.stderr.splitlines() if ln.startswith("[morna] split_mm level")]
     assert out["default"] == out["no_mm"] == out["no_qf"] == out["no_dense"] == out["no_order"] == out["no_lists"], out
+    assert out["default"] == out["fused_traverse"] == out["no_spread"], out
     assert int(out["default"][2]) >= 2                       # at least two levels went through the contraction
     assert open_lines, "the matrix-core split did not run"
     print("\n".join(open_lines))                             # pytest -s: the open-pair share per level
