@@ -84,14 +84,17 @@ __global__ __launch_bounds__(1024) void col_scan_kernel(const int32_t *__restric
 #define ACC_THREADS 1024
 
 // Lines bucketed by column, file order kept inside a bucket: a stable counting sort of the J lines by column.
-//   col_rank_kernel   one workgroup per chunk of 1024 consecutive lines: rank of a line among the EARLIER lines
+//   col_rank_kernel   one workgroup per chunk of CR_LINES consecutive lines: rank of a line among the EARLIER lines
 //                     of its chunk with the same column (compare against the chunk's columns in LDS), and the
-//                     chunk's line count per column (chunk_cnt[chunk][column], zeroed before)
-//   col_base_kernel   per column: exclusive prefix of those counts over the chunks, in place
-//   col_place_kernel  lines[off[column] + base[chunk][column] + rank] = line
-// (The first version scanned all J lines once per column: 2.1e8 comparisons at C3, 0.4 ms.)
-#define CR_LINES 1024
-__global__ __launch_bounds__(CR_LINES) void col_rank_kernel(const int32_t *__restrict__ col, int64_t J, int32_t dim,
+//                     chunk's line count per column (chunk_cnt[column][chunk], zeroed before)
+//   col_base_kernel   per column: exclusive prefix of those counts over the chunks, in place (a wave per column)
+//   col_place_kernel  lines[off[column] + base[column][chunk] + rank] = line
+// (The first version scanned all J lines once per column: 2.1e8 comparisons at C3, 0.4 ms.  Round 3: chunks of 256 lines
+// instead of 1024 -- a shard of the row cut keeps all ~J lines of the file, so at 6250 rows this bucketing, 69 workgroups
+// whose last thread compared against 1023 earlier lines, was 0.17 of the feature build's 0.29 ms -- and the counts by column
+// first, so that a column's prefix is a coalesced wave scan: 0.22 -> 0.06 ms for the four kernels.)
+#define CR_LINES 256
+__global__ __launch_bounds__(CR_LINES) void col_rank_kernel(const int32_t *__restrict__ col, int64_t J, int32_t n_chunks,
                                                             int32_t *__restrict__ rank, int32_t *__restrict__ chunk_cnt)
 {
     __shared__ __attribute__((aligned(16))) int32_t s_col[CR_LINES];
@@ -110,29 +113,39 @@ __global__ __launch_bounds__(CR_LINES) void col_rank_kernel(const int32_t *__res
     }
     for (int k = k4 * 4; k < i; k++) r += s_col[k] == my;
     rank[j] = r;
-    atomicAdd(&chunk_cnt[(int64_t)blockIdx.x * dim + my], 1);
+    atomicAdd(&chunk_cnt[(int64_t)my * n_chunks + blockIdx.x], 1);
 }
 
+// one wave per column: chunk_cnt[column][0 .. n_chunks) -> its exclusive prefix
 __global__ __launch_bounds__(256) void col_base_kernel(int32_t *__restrict__ chunk_cnt, int32_t n_chunks, int32_t dim)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int c = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
     if (c >= dim) return;
+    int32_t *cnt = chunk_cnt + (int64_t)c * n_chunks;
     int run = 0;
-    for (int k = 0; k < n_chunks; k++) {
-        const int t = chunk_cnt[(int64_t)k * dim + c];
-        chunk_cnt[(int64_t)k * dim + c] = run;
-        run += t;
+    for (int k0 = 0; k0 < n_chunks; k0 += WAVE) {
+        const int k = k0 + lane;
+        const int t = k < n_chunks ? cnt[k] : 0;
+        int incl = t;   // inclusive scan over the wave
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const int o = __shfl_up(incl, off, WAVE);
+            if (lane >= off) incl += o;
+        }
+        if (k < n_chunks) cnt[k] = run + incl - t;
+        run += __shfl(incl, WAVE - 1, WAVE);
     }
 }
 
-__global__ __launch_bounds__(256) void col_place_kernel(const int32_t *__restrict__ col, int64_t J, int32_t dim,
+__global__ __launch_bounds__(256) void col_place_kernel(const int32_t *__restrict__ col, int64_t J, int32_t n_chunks,
                                                         const int32_t *__restrict__ rank, const int32_t *__restrict__ chunk_base,
                                                         const int32_t *__restrict__ off, int32_t *__restrict__ lines)
 {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= J) return;
     const int32_t c = col[j];
-    lines[off[c] + chunk_base[(j / CR_LINES) * dim + c] + rank[j]] = (int32_t)j;
+    lines[off[c] + chunk_base[(int64_t)c * n_chunks + j / CR_LINES] + rank[j]] = (int32_t)j;
 }
 
 // One workgroup per line: does any sample id repeat inside the line?  (Internal
@@ -939,11 +952,11 @@ int build_features(morna_index *h, int64_t n_items)
             const int32_t n_chunks = (int32_t)((J + CR_LINES - 1) / CR_LINES);
             hipLaunchKernelGGL(zero_i32_kernel, dim3((unsigned)std::min<int64_t>(((int64_t)n_chunks * D + 255) / 256, 2048)), dim3(256), 0,
                                h->stream, chunk_cnt, (int64_t)n_chunks * D);
-            hipLaunchKernelGGL(col_rank_kernel, dim3((unsigned)n_chunks), dim3(CR_LINES), 0, h->stream, col.p, J, (int32_t)D,
+            hipLaunchKernelGGL(col_rank_kernel, dim3((unsigned)n_chunks), dim3(CR_LINES), 0, h->stream, col.p, J, n_chunks,
                                line_rank, chunk_cnt);
-            hipLaunchKernelGGL(col_base_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, h->stream, chunk_cnt, n_chunks,
-                               (int32_t)D);
-            hipLaunchKernelGGL(col_place_kernel, dim3((unsigned)((J + 255) / 256)), dim3(256), 0, h->stream, col.p, J, (int32_t)D,
+            hipLaunchKernelGGL(col_base_kernel, dim3((unsigned)((D + 256 / WAVE - 1) / (256 / WAVE))), dim3(256), 0, h->stream,
+                               chunk_cnt, n_chunks, (int32_t)D);
+            hipLaunchKernelGGL(col_place_kernel, dim3((unsigned)((J + 255) / 256)), dim3(256), 0, h->stream, col.p, J, n_chunks,
                                line_rank, chunk_cnt, col_off.p, col_lines.p);
         }
         if (J > 0) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
@@ -961,7 +974,10 @@ int build_features(morna_index *h, int64_t n_items)
         }
         // the column image becomes the rows, and the rows' canonical norms come out of the same pass (MORNA_FUSED_NORMS=0:
         // transpose, then row_norms_kernel over the finished rows)
-        static const bool fused = !(getenv("MORNA_FUSED_NORMS") && atoi(getenv("MORNA_FUSED_NORMS")) == 0);
+        // (the fused pass is one workgroup per 64 positions: below one workgroup per CU -- a 6250-row shard of the 8-way cut --
+        // the 2-D transpose and a norm pass of their own are faster: 0.34 -> 0.29 ms for that shard's feature build)
+        static const int fused_env = getenv("MORNA_FUSED_NORMS") ? atoi(getenv("MORNA_FUSED_NORMS")) : -1;
+        const bool fused = fused_env >= 0 ? fused_env != 0 : (n_items + TT - 1) / TT >= (int64_t)h->n_cus;
         const int32_t *item_of = by_order ? (const int32_t *)h->item_at.p : (const int32_t *)nullptr;
         if (fused) {
             MORNA_TRY(h->norm2.alloc((size_t)n_items));
