@@ -7,6 +7,7 @@
 // ids, cumulative junction frequencies, idf = log(sample_count / freq) from libm.
 // The Python tokenising loop is the reference's real end-to-end cost (SURVEY.md
 // section 8f N1); this does the same work at I/O speed.
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -605,9 +606,12 @@ int morna_lines_save(const morna_lines *L, const char *path, const int64_t *tag)
         set_error("lines_save: null argument");
         return MORNA_E_INVALID;
     }
-    FILE *f = fopen(path, "wb");
+    // written under a name of its own and renamed into place: several ranks of `index --shards --cache` may write the
+    // cache of the same file at once, and a reader must never see half of one
+    const std::string tmp = std::string(path) + ".tmp." + std::to_string((long long)getpid());
+    FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) {
-        set_error("Unable to open %s for writing", path);
+        set_error("Unable to open %s for writing", tmp.c_str());
         return MORNA_E_IO;
     }
     int64_t counts[8];
@@ -624,7 +628,9 @@ int morna_lines_save(const morna_lines *L, const char *path, const int64_t *tag)
               put_vec(f, L->row_ptr) && put_vec(f, L->item_ids) && put_vec(f, L->cov) && put_vec(f, L->idf) &&
               put_vec(f, L->ext_ids) && put_vec(f, L->freq_vals) && put_vec(f, klen) && put_vec(f, kbytes);
     ok = (fclose(f) == 0) && ok;
+    ok = ok && rename(tmp.c_str(), path) == 0;
     if (!ok) {
+        (void)remove(tmp.c_str());
         set_error("short write to %s", path);
         return MORNA_E_IO;
     }
