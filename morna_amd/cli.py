@@ -50,7 +50,9 @@ def add_search_parameters(subparser):
                            help='the number of nearest neighbor results to return')
     subparser.add_argument('-rl', '--rawlist', action='store_const', const=True, default=False,
                            help='regurgitate junction list for input sample instead of performing search')
-    subparser.add_argument('--device', type=int, default=0, help='HIP device ordinal')
+    subparser.add_argument('--device', type=str, default='0',
+                           help='HIP device ordinal; for an index built with --shards also a list, "0,1,2,3": the shards are '
+                                'dealt to these devices in turn')
 
 
 def build_parser():
@@ -112,7 +114,8 @@ def main(argv=None, stdin=None, stdout=None):
         return 2
     from .search import MornaSearch, results_output
     from .streams import junctions_from_bed_stream, junctions_from_raw_stream, junctions_from_sam_stream
-    searcher = MornaSearch(basename=args.basename, device=args.device)
+    devices = [int(d) for d in str(args.device).split(',')]
+    searcher = MornaSearch(basename=args.basename, device=devices if len(devices) > 1 else devices[0])
     if args.query_id is not None:                              # morna.py:1358-1365
         results = searcher.search_member_n(args.query_id, args.results, args.search_k,
                                            include_distances=args.distances, meta_db=args.metadata)
