@@ -242,7 +242,9 @@ int morna_merge_topk_packed(morna_index *h, const int32_t *gathered_dev, int32_t
  * call it with the same nq / k / search_k (and the same queries, where queries are passed).  Data path: per-shard search
  * -> ncclAllGather of the per-shard top-k (Q * k * 8 bytes per rank; exact: Q * (12 k + 4)) on the handle's stream ->
  * merge kernel; every rank receives the same merged answer (global ids).  RCCL is loaded at run time; without it
- * morna_comm_init fails and nothing falls back to the host.
+ * morna_comm_init fails and nothing falls back to the host.  Arguments are checked before the first collective of a call;
+ * as in any RCCL program, a call that fails on ONE rank only (an item number out of that shard's range) leaves the other
+ * ranks waiting in the collective: validate rank-local input before calling.
  *   morna_comm_unique_id   ncclGetUniqueId: ONE rank makes the id, the caller hands the 128 bytes to the others (any
  *                          channel: a file, MPI, torch.distributed's store)
  *   morna_comm_init        ncclCommInitRank on the handle's device; world <= 64

@@ -1889,7 +1889,7 @@ int exact_search_any(morna_index *h, const double *q_host, const float *q_dev, c
     double *d_dist = (double *)p; p += s_dist;
     int32_t *d_cnt = (int32_t *)p; p += s_b4;
     std::vector<int32_t> h_ncand((size_t)batch);
-    int32_t cap = std::max<int32_t>(std::max(64, 4 * k), h->ex_cap);
+    int32_t cap = std::max<int32_t>(std::max(64, 4 * k), h->ex_cap), need_max = 0;
     for (int64_t q0 = 0; q0 < nq; q0 += batch) {
         const int64_t nb = std::min(batch, nq - q0);
         if (q_host) {
@@ -1934,10 +1934,10 @@ int exact_search_any(morna_index *h, const double *q_host, const float *q_dev, c
             HIP_TRY(hipStreamSynchronize(h->stream));
             int32_t need = 0;
             for (int64_t i = 0; i < nb; i++) need = std::max(need, h_ncand[(size_t)i]);
+            need_max = std::max(need_max, need);
             if (need <= cap) break;
             cap = need;   // huge tie groups at the boundary: make room for all of them
         }
-        h->ex_cap = cap;   // the next call starts with the room this one needed
         hipLaunchKernelGGL(exact_rerank_kernel, dim3((unsigned)nb), dim3(RR_THREADS), 0, h->stream, h->X.p, D, dpad,
                            Qd, h->ex_cand.p, ncand, cap, k, h->ex_cdist.p, d_ids, d_dist, d_cnt);
         HIP_TRY(hipGetLastError());
@@ -1964,6 +1964,8 @@ int exact_search_any(morna_index *h, const double *q_host, const float *q_dev, c
             if (count_out) memcpy(count_out + q0, h->host_out + s_ids + s_dist, (size_t)nb * 4);
         }
     }
+    h->ex_cap = need_max;   // the next call starts with the room this one needed (no more: one query with a tie of thousands
+                            // does not size every later call)
     return MORNA_OK;
 }
 
