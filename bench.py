@@ -190,7 +190,7 @@ def query_sweep(args, index, items, k, st):
         cand = max(rows - dots - 1, 0.0)
         e = {"nq": nq, "ms_per_call": ms, "us_per_query": 1e3 * ms / nq, "kernels_ms": tq["ms"],
              "rows_touched_per_query": rows,
-             "path": "whole-batch fp16 contraction + traversal" if (nq >= 64 and nq * min(st["leaf_capacity"], rows) >= 2 * st["n_items"])
+             "path": "whole-batch fp16 contraction || root margins by query groups + one-wave descents" if (nq >= 40 and nq * min(st["leaf_capacity"], rows) >= 2 * st["n_items"])
                      else "spread: a wave per (query, tree) root margin, one wave descends, a wave per candidate (canonical fp32 dot), "
                           "one workgroup ranks" if nq < 64 else "one workgroup per query, per-candidate fp16 filter"}
         if nq == 1:

@@ -988,10 +988,13 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
     static const bool filter_on = !(getenv("MORNA_QUERY_FILTER") && atoi(getenv("MORNA_QUERY_FILTER")) == 0);
     static const bool dense_on = !(getenv("MORNA_QUERY_DENSE") && atoi(getenv("MORNA_QUERY_DENSE")) == 0);
     // fewer queries than would give every CU a workgroup: the spread form (MORNA_QUERY_SPREAD=0: one workgroup per query)
-    const bool spread = nq < 64 && !(getenv("MORNA_QUERY_SPREAD") && atoi(getenv("MORNA_QUERY_SPREAD")) == 0);
-    const bool use_filter = !spread && filter_on && cap > 4 * (int64_t)k;
+    const bool spread_on = !(getenv("MORNA_QUERY_SPREAD") && atoi(getenv("MORNA_QUERY_SPREAD")) == 0);
+    const bool filter_pays = filter_on && cap > 4 * (int64_t)k;
     // the whole-batch contraction reads every fp16 row once; the gather form reads min(cap, ~K) rows per query
-    auto dense_pays = [&](int64_t nb) { return nb >= 64 && nb * std::min<int64_t>(cap, h->K) >= 2 * N; };
+    // (C3, 48 / 63 queries: 207 us through the contraction, 231 / 282 us through the spread form; 32: the spread form's 174 us)
+    auto dense_pays = [&](int64_t nb) { return nb >= 40 && nb * std::min<int64_t>(cap, h->K) >= 2 * N; };
+    const bool spread = spread_on && nq < 64 && !(filter_pays && dense_on && dense_pays(nq));
+    const bool use_filter = !spread && filter_pays;
     const bool may_dense = use_filter && dense_on && dense_pays(nq);
 
     const size_t per_q = (size_t)h->n_nodes * 8 + (size_t)cap * 16 + (q_host ? (size_t)h->dpad * 6 + 16 : 0) +
