@@ -50,5 +50,17 @@ for r in range(rounds):
                 continue
             assert ids[qi, :len(rid)].astype(np.int64).tolist() == rid.tolist(), ("exact ids", D, N, nq, qi)
             assert d[qi, :len(rid)].tobytes() == rd.tobytes(), ("exact dist", D, N, nq, qi)
+    # the in-library sharded entry points on a communicator of one rank: the plain answers (ids are global = local here)
+    a.comm_init(AnnoyIndex.comm_unique_id(), 0, 1)
+    for nq in (1, 7, 45):
+        items = rng.integers(0, N, nq).astype(np.int32)
+        k = int(min(N, 9))
+        want = a.get_nns_by_item_batch(items, k, 50)
+        got = a.get_nns_by_item_sharded(items, k, 50, n_each=[nq])
+        assert got[0].tolist() == want[0].tolist() and got[1].tobytes() == want[1].tobytes() and got[2].tolist() == want[2].tolist()
+        want = a.exact_search_by_item_batch(items, k)
+        got = a.exact_search_by_item_sharded(items, k, [nq])
+        assert got[0].tolist() == want[0].tolist() and got[1].tobytes() == want[1].tobytes() and got[2].tolist() == want[2].tolist()
+    a.comm_destroy()
     print("round %d ok: D=%d N=%d T=%d" % (r, D, N, T), flush=True)
 print("stress ok")
