@@ -123,6 +123,28 @@ def main():
         if r.returncode != 0:
             res["cli_stderr"] = r.stderr[-500:]
         res["samples_per_s_end_to_end_cli"] = a.samples / res["cli_index_wall_s"]
+        # ---- `morna search` end to end on that index: one query per process, as the reference is used (morna.py:1345-1484)
+        if r.returncode == 0:
+            from morna_amd.search import MornaSearch
+            t0 = time.perf_counter()
+            ms = MornaSearch(basename=os.path.join(tmp, "cli"))
+            t_load = time.perf_counter() - t0
+            some_id = next(iter(ms.internal_id_map))
+            t0 = time.perf_counter()
+            ms.annoy_index.get_nns_by_item(ms.internal_id_map[some_id], 20, 100, include_distances=True)
+            t_first = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            ms.annoy_index.get_nns_by_item(ms.internal_id_map[some_id], 20, 100, include_distances=True)
+            t_second = time.perf_counter() - t0
+            del ms
+            t0 = time.perf_counter()
+            r2 = subprocess.run([sys.executable, "-m", "morna_amd.cli", "search", "-x", os.path.join(tmp, "cli"), "-q", str(some_id),
+                                 "-d"], cwd=ROOT, capture_output=True, text=True)
+            res["cli_search_by_member"] = {"wall_s": time.perf_counter() - t0, "rc": r2.returncode,
+                                           "result_lines": len([ln for ln in r2.stdout.splitlines() if ln[:1].isdigit()]),
+                                           "in_process": {"load_index_file_set_s": t_load, "first_query_s": t_first,
+                                                          "second_query_s": t_second},
+                                           "index_bytes": os.path.getsize(os.path.join(tmp, "cli.annoy.mor"))}
         # ---- what the binary pre-tokenised cache buys: `index --cache` twice over the same file -- the first
         # run parses and writes the cache, the second (other --n-trees, as a user tuning the index would) reads it back
         cache = os.path.join(tmp, "lines.cache")
