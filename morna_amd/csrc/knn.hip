@@ -1169,8 +1169,6 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
             // query; the kernel counts them into d_stat[0], resolve_timers() prices them
             ScopedTimer tm(h, MORNA_T_QUERY, 0);
             if (dense) {
-                HIP_TRY(hipEventRecord(h->ev_fork, h->stream));   // the query vectors / item ids are in place
-                HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
                 const _Float16 *q16 = P.X16;
                 const int32_t *qrow = P.items;
                 if (q_host) {
@@ -1180,6 +1178,8 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
                 } else {
                     P.qn16 = P.xn16; P.qe16 = P.xe16; P.qscale = P.xscale;
                 }
+                HIP_TRY(hipEventRecord(h->ev_fork, h->stream));   // the query vectors (and their fp16 image) / item ids are in place
+                HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
                 ScopedTimer tf(h, MORNA_T_QUERY_FILTER, 2 * (int64_t)nb * N * h->dpad);   // "bytes" = executed flops
                 // 256 x 256 tiles for as many 256-row tiles as make whole rounds of the chip (one workgroup per CU), the
                 // 128 x 128 form for the rows behind them (MORNA_QUERY_BIG=0: for all rows)
@@ -1203,8 +1203,10 @@ int query_batch(morna_index *h, const float *q_host, int64_t q_stride, const int
                 if (P.big_rows < N) {
                     const unsigned n_ct = (unsigned)((nb + MM16_TILE - 1) / MM16_TILE), n_rt = (unsigned)((N - P.big_rows + 127) / 128);
                     HIP_TRY(hipFuncSetAttribute((const void *)query_scores_kernel<128, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, MM16_LDS));
+                    // (the rows behind the whole rounds of the 256 x 256 form: on the side stream, in front of the traversal,
+                    // when the large form runs -- behind it on the main stream they were 0.05 ms of the batch's critical path)
                     hipLaunchKernelGGL((query_scores_kernel<128, 64, 2>), dim3(8u * ((n_rt + 7) / 8) * n_ct), dim3(MM16_THREADS), MM16_LDS,
-                                       h->stream, P.X16, N, h->dpad, q16, qrow, (int32_t)nb, scores, P.big_rows);
+                                       big_tiles > 0 ? h->stream2 : h->stream, P.X16, N, h->dpad, q16, qrow, (int32_t)nb, scores, P.big_rows);
                 }
                 P.scores = scores;
             }
