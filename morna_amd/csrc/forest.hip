@@ -472,6 +472,13 @@ __global__ __launch_bounds__(256) void two_means_strip_kernel(const float *__res
     float r2p = tm_recip(2), r2q = tm_recip(2);   // RN32 of 1 / (ic + 1), 1 / (jc + 1)
     float u = exchange3(chain(p, x[0]), chain(q, x[0]), 0.f);   // the dots of step 0
     int upd_prev = 0;
+#ifdef MORNA_TM_PROBE
+    long long c_decide = 0, c_update = 0, c_fetch = 0, c_dots = 0, c_t;
+#define TMP(acc) do { const long long n_ = clock64(); acc += n_ - c_t; c_t = n_; } while (0)
+    c_t = clock64();
+#else
+#define TMP(acc) do { } while (0)
+#endif
     for (int l0 = 0; l0 < TM_ITERS; l0 += DEPTH) {
 #pragma unroll
         for (int r = 0; r < DEPTH; r++) {
@@ -489,6 +496,7 @@ __global__ __launch_bounds__(256) void two_means_strip_kernel(const float *__res
             const double r1 = __longlong_as_double(r1_bits);
             int upd = 0;
             if (norm > 0.f) upd = di < dj ? 1 : (dj < di ? 2 : 0);
+            TMP(c_decide);
             // ---- update this wave's strip of the chosen centroid, and its chain of the new self-dot
             float cc = 0.f;
             if (upd == 1) {
@@ -508,19 +516,28 @@ __global__ __launch_bounds__(256) void two_means_strip_kernel(const float *__res
                 r2q = tm_recip(jc + 1);
             }
             upd_prev = upd;
+            TMP(c_update);
             // ---- slot r is free: the row DEPTH steps ahead goes there.  (Past step 199 these fetch rows nobody
             // uses: the stream has more draws and every index is valid.)
             const int32_t it_new = it_ahead;
             load_strip(it_new, x[r]);
             ri[r] = vgather(rowinfo, (uint32_t)it_new);
             it_ahead = vgather(items, rng.index((uint32_t)t.count));
+            TMP(c_fetch);
             // ---- the dots of the next step, with the row in the next slot
             constexpr int DUMMY = 0;
             (void)DUMMY;
             const int rn = (r + 1) % DEPTH;
             u = exchange3(chain(p, x[rn]), chain(q, x[rn]), cc);
+            TMP(c_dots);
         }
     }
+#ifdef MORNA_TM_PROBE
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("[tm_strip probe] cycles per step: decide %lld update %lld fetch %lld dots+exchange %lld (nodes %d)\n",
+               c_decide / TM_ITERS, c_update / TM_ITERS, c_fetch / TM_ITERS, c_dots / TM_ITERS, (int)gridDim.x);
+#endif
+#undef TMP
     // create_split: n = normalize(p - q), each wave its strip
 #pragma unroll
     for (int s = 0; s < NS; s++) EW4(p[s], p[s].x - q[s].x, p[s].y - q[s].y, p[s].z - q[s].z, p[s].w - q[s].w);
