@@ -41,6 +41,8 @@ typedef struct morna_index morna_index;
 /* AnnoyIndex(dim, metric='angular')                          morna.py:166, 543, 1171 */
 int morna_index_create(int32_t dim, int32_t device, morna_index **out);
 int morna_index_destroy(morna_index *h);
+/* HIP devices the library can create indexes on (0 and MORNA_E_HIP when there is none: the library has no CPU path) */
+int morna_device_count(int32_t *count_out);
 const char *morna_last_error(void);
 
 /* mmh3.hash(key) -- host mirror of the device hash            morna.py:369, 591, 625 */

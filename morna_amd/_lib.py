@@ -31,6 +31,7 @@ _p, _i32, _i64, _u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
 SIGNATURES = {
     "morna_index_create": (C.c_int, [_i32, _i32, C.POINTER(_p)]),
     "morna_index_destroy": (C.c_int, [_p]),
+    "morna_device_count": (C.c_int, [C.POINTER(_i32)]),
     "morna_last_error": (C.c_char_p, []),
     "morna_hash32": (_i32, [_p, _i64]),
     "morna_add_item": (C.c_int, [_p, _i32, _p]),
@@ -118,6 +119,13 @@ def check(rc):
     if rc != OK:
         msg = lib().morna_last_error().decode("utf-8", "replace")
         raise _EXC.get(rc, RuntimeError)(msg)
+
+
+def device_count():
+    """HIP devices the library sees (raises when there is none)."""
+    n = _i32(0)
+    check(lib().morna_device_count(C.byref(n)))
+    return int(n.value)
 
 
 def ptr(a):

@@ -102,9 +102,11 @@ def main(argv=None, stdin=None, stdout=None):
     if args.subparser_name == 'index':
         import os
         from .index import go_index
-        rank, device = None, args.device
+        rank, device = None, int(str(args.device).split(',')[0])
         if args.shards > 1 and int(os.environ.get("WORLD_SIZE", "1")) == args.shards:   # one process per GPU
-            rank, device = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+            from ._lib import device_count
+            rank = int(os.environ.get("RANK", "0"))
+            device = int(os.environ.get("LOCAL_RANK", "0")) % device_count()   # (fewer GPUs than ranks: the ranks share them)
         go_index(args.intropolis, args.basename, args.features, args.n_trees, args.sample_count,
                  args.sample_threshold, args.buffer_size, args.verbose, args.metafile, device=device,
                  native=not args.python_parse, cache=args.cache, shards=args.shards, rank=rank)

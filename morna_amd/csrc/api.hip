@@ -152,6 +152,19 @@ int morna_index_create(int32_t dim, int32_t device, morna_index **out)
     return MORNA_OK;
 }
 
+int morna_device_count(int32_t *count_out)
+{
+    if (!count_out) return MORNA_E_INVALID;
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    *count_out = e == hipSuccess ? n : 0;
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (%s): libmorna_hip has no CPU path", hipGetErrorString(e));
+        return MORNA_E_HIP;
+    }
+    return MORNA_OK;
+}
+
 int morna_index_destroy(morna_index *h)
 {
     if (!h) return MORNA_OK;

@@ -293,3 +293,43 @@ def test_cli_index_shards_then_search_equals_unsharded(tmp_path):
     assert s3.annoy_index.get_item_vector(N - 1) == s1.annoy_index.get_item_vector(N - 1)
     with pytest.raises(IndexError):
         s3.annoy_index.get_item_vector(N)
+
+
+def test_cli_index_shards_one_process_per_rank_under_torchrun(tmp_path):
+    """`morna index --shards 2` launched as `torch.distributed.run --nproc-per-node 2`: every rank parses the file (both
+    write the pre-tokenised cache: it is renamed into place, so neither reads half of the other's), builds ITS shard on its
+    device (here both share the one GPU) and saves it; rank 0 writes the global files.  The file set equals the one a single
+    process writes, and its stacked matrices are the unsharded index's."""
+    import socket
+    import subprocess
+    import sys
+    from morna_amd import cli
+    from morna_amd.search import MornaSearch
+    from morna_amd.synth import synthetic_intropolis
+    d = synthetic_intropolis(900, J=1200)
+    src = str(tmp_path / "i.tsv.gz")
+    lines = []
+    for j, k in enumerate(d["keys"]):
+        lo, hi = d["row_ptr"][j], d["row_ptr"][j + 1]
+        lines.append("\t".join(k.split(" ") + ["+", "GT", "AG", ",".join(map(str, d["samples"][lo:hi])),
+                                               ",".join(map(str, d["cov"][lo:hi]))]) + "\n")
+    _write_gz(src, lines)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    two, one = str(tmp_path / "two"), str(tmp_path / "one")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), "-m", "morna_amd.cli", "index", "--intropolis", src, "-x", two,
+                        "--features", "96", "--n-trees", "5", "-t", "40", "--shards", "2", "--cache", str(tmp_path / "i.cache")],
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert cli.main(["index", "--intropolis", src, "-x", one, "--features", "96", "--n-trees", "5", "-t", "40"]) == 0
+    a, b = MornaSearch(one), MornaSearch(two)
+    assert b.annoy_index.offsets.tolist() == [0, 450, 900]
+    assert np.concatenate([sh.get_items() for sh in b.annoy_index.shards]).tobytes() == a.annoy_index.get_items().tobytes()
+    assert a.internal_id_map == b.internal_id_map and dict(a.sample_frequencies) == dict(b.sample_frequencies)
+    q = a.annoy_index.get_item_vector(123)
+    a.query_sample = b.query_sample = [float(v) for v in q]
+    assert a.exact_search_nn(8) == b.exact_search_nn(8)
