@@ -42,6 +42,10 @@ int main(int argc, char **argv)
     /* mmh3.hash("foo") = -156908512, mmh3's documented answer */
     EXPECT(morna_hash32((const uint8_t *)"foo", 3) == -156908512);
     morna_index *h = NULL, *g = NULL;
+    int32_t n_dev = 0;
+    CK(morna_device_count(&n_dev));
+    EXPECT(n_dev >= 1);
+    EXPECT(morna_index_create(F, n_dev, &h) == MORNA_E_INVALID);   /* a device that is not there */
     CK(morna_index_create(F, 0, &h));
     static double row[F];
     static float centers[12][F];
