@@ -117,13 +117,57 @@ def main(argv=None, stdin=None, stdout=None):
     from .search import MornaSearch, results_output
     from .streams import junctions_from_bed_stream, junctions_from_raw_stream, junctions_from_sam_stream
     devices = [int(d) for d in str(args.device).split(',')]
-    searcher = MornaSearch(basename=args.basename, device=devices if len(devices) > 1 else devices[0])
+    import os
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    dist = None
+    if world > 1 and os.path.exists(args.basename + ".shards.mor"):
+        # torchrun with one process per shard: every rank runs this function with the same query (rank 0 reads the stream
+        # and hands it over) and calls the same collectives; rank 0 prints
+        import io
+        import torch
+        import torch.distributed as dist
+        from ._lib import device_count
+        n_dev = device_count()
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        backend = "nccl" if n_dev >= int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) else "gloo"   # RCCL wants a GPU per rank
+        torch.cuda.set_device(local % n_dev)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        searcher = MornaSearch(basename=args.basename, device=local % n_dev, rank=rank, world=world)
+        if rank != 0:
+            stdout = io.StringIO()
+    else:
+        searcher = MornaSearch(basename=args.basename, device=devices if len(devices) > 1 else devices[0])
+    try:
+        return _search(args, searcher, stdin, stdout, dist, rank)
+    finally:
+        if dist is not None:
+            searcher.annoy_index.close()
+            dist.destroy_process_group()
+
+
+def _search(args, searcher, stdin, stdout, dist, rank):
+    from .search import results_output
+    from .streams import junctions_from_bed_stream, junctions_from_raw_stream, junctions_from_sam_stream
     if args.query_id is not None:                              # morna.py:1358-1365
-        results = searcher.search_member_n(args.query_id, args.results, args.search_k,
-                                           include_distances=args.distances, meta_db=args.metadata)
+        if dist is not None and rank != 0:
+            import contextlib
+            with contextlib.redirect_stdout(stdout):           # ("querying by sample id ..." is rank 0's to print)
+                results = searcher.search_member_n(args.query_id, args.results, args.search_k,
+                                                   include_distances=args.distances, meta_db=args.metadata)
+        else:
+            results = searcher.search_member_n(args.query_id, args.results, args.search_k,
+                                               include_distances=args.distances, meta_db=args.metadata)
         results_output(results, stdout)
         return 0
-    if args.format == "sam":
+    if dist is not None:
+        # only rank 0 has the stream: it parses it and every rank walks the same list of junctions
+        box = [None]
+        if rank == 0:
+            gen = {"sam": junctions_from_sam_stream, "bed": junctions_from_bed_stream, "raw": junctions_from_raw_stream}[args.format]
+            box[0] = list(gen(stdin))
+        dist.broadcast_object_list(box, src=0)
+        junction_generator = iter(box[0])
+    elif args.format == "sam":
         junction_generator = junctions_from_sam_stream(stdin)
     elif args.format == "bed":
         junction_generator = junctions_from_bed_stream(stdin)

@@ -34,7 +34,9 @@ def results_output(results, out=None):
 
 
 class MornaSearch(object):
-    def __init__(self, basename, device=0):
+    def __init__(self, basename, device=0, rank=None, world=None):
+        """rank / world: one process per shard of an index built with --shards (shards.DistShards); None: this process
+        holds the whole index (or all of its shards, shards.LocalShards)."""
         self.basename = basename
         with open(basename + ".stats.mor") as stats_stream:
             self.sample_count = int(stats_stream.readline())
@@ -42,7 +44,10 @@ class MornaSearch(object):
             self.dim = int(stats_stream.readline())
         self.query = defaultdict(int)
         self.query_sample = [0.0 for _ in range(self.dim)]
-        if os.path.exists(basename + ".shards.mor"):           # written by `morna index --shards G` (index.py)
+        if world is not None and world > 1:                    # torchrun: this process serves shard `rank`
+            from .shards import DistShards
+            self.annoy_index = DistShards(basename, self.dim, rank, world, device=device)
+        elif os.path.exists(basename + ".shards.mor"):         # written by `morna index --shards G` (index.py)
             from .shards import LocalShards
             self.annoy_index = LocalShards(basename, self.dim, device=device)
         else:

@@ -137,3 +137,77 @@ class LocalShards(object):
                                        np.stack([p[1] for p in per]), n)
         failed = np.stack([p[2] for p in per]).min(axis=0) < 0     # one shard's "the reference raises" fails the query
         return ids, d, np.where(failed, -1, cnt).astype(np.int32)
+
+
+class DistShards(object):
+    """One shard per process (torchrun: WORLD_SIZE = the number of shards of `<basename>.shards.mor`), behind the same part
+    of the AnnoyIndex surface as LocalShards.  Every method is a COLLECTIVE: all ranks call it with the same arguments (the
+    command line does: `morna search` under torchrun) and all receive the same answer.  The exchange is dist.ShardedSearch's:
+    inside the library over RCCL when the process group's backend is "nccl", through the host over gloo otherwise."""
+
+    def __init__(self, basename, dim, rank, world, device=0, group=None):
+        from .annoy import AnnoyIndex
+        from .dist import ShardedSearch
+        from .index import shard_basename
+        with open(basename + ".shards.mor") as fh:
+            n_shards = int(fh.readline())
+            self.offsets = np.array([int(t) for t in fh.readline().split()], np.int64)
+        if n_shards != world or len(self.offsets) != world + 1:
+            raise IOError("%s.shards.mor lists %d shards, %d processes were started" % (basename, n_shards, world))
+        self.f, self.rank, self.world = int(dim), rank, world
+        self.shard = AnnoyIndex(self.f, metric="angular", device=device)
+        self.shard.load(shard_basename(basename, rank, world) + ".annoy.mor")
+        self.search = ShardedSearch(self.shard, rank, world, self.shard.get_n_items(), group=group)
+        if self.search.offsets.tolist() != self.offsets.tolist():
+            raise IOError("the shards loaded by the ranks do not add up to %s.shards.mor" % basename)
+
+    def close(self):
+        self.search.close()
+
+    def get_n_items(self):
+        return int(self.offsets[-1])
+
+    def _owner(self, i):
+        if i < 0 or i >= self.offsets[-1]:
+            raise IndexError("Item index %d out of range [0, %d)" % (i, self.offsets[-1]))
+        g = int(np.searchsorted(self.offsets, i, side="right")) - 1
+        return g, int(i - self.offsets[g])
+
+    @staticmethod
+    def _one(ids, d, cnt, include_distances):
+        m = int(cnt[0])
+        out = [int(x) for x in ids[0, :m]]
+        return (out, [float(x) for x in d[0, :m]]) if include_distances else out
+
+    def get_nns_by_vector(self, vector, n, search_k=-1, include_distances=False):
+        v = np.ascontiguousarray(vector, dtype=np.float32)
+        if v.shape != (self.f,):
+            raise IndexError("Vector has wrong length (expected %d, got %d)" % (self.f, v.size))
+        return self._one(*self.search.get_nns_by_vector(v[None, :], n, search_k), include_distances=include_distances)
+
+    def get_nns_by_item(self, i, n, search_k=-1, include_distances=False):
+        """The owner of global item i hands over its stored row; every shard answers (morna.py:762, 769)."""
+        g, local = self._owner(int(i))
+        mine = np.array([local] if g == self.rank else [], np.int32)
+        n_each = [1 if r == g else 0 for r in range(self.world)]
+        return self._one(*self.search.get_nns_by_local_items(mine, n, search_k, n_each=n_each), include_distances=include_distances)
+
+    def get_item_vector(self, i):
+        g, local = self._owner(int(i))
+        mine = np.array([local] if g == self.rank else [], np.int32)
+        rows = self.search._gather_rows(mine, [1 if r == g else 0 for r in range(self.world)]) if not self.search.in_library \
+            else self._row_via_exact(mine, g)
+        return [float(x) for x in rows[0]]
+
+    def _row_via_exact(self, mine, g):
+        # (library path: the owner reads its row and the ranks exchange it through the process group)
+        import torch
+        import torch.distributed as dist
+        row = torch.zeros(self.f, dtype=torch.float32, device=self.search.device)
+        if len(mine):
+            row = torch.from_numpy(self.shard.get_item_vectors(mine)[0]).to(self.search.device)
+        dist.broadcast(row, src=g, group=self.search.group)
+        return row.cpu().numpy()[None, :]
+
+    def exact_search_batch(self, Q, n):
+        return self.search.exact_search(np.ascontiguousarray(Q, dtype=np.float64), n)

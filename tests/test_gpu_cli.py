@@ -333,3 +333,55 @@ def test_cli_index_shards_one_process_per_rank_under_torchrun(tmp_path):
     q = a.annoy_index.get_item_vector(123)
     a.query_sample = b.query_sample = [float(v) for v in q]
     assert a.exact_search_nn(8) == b.exact_search_nn(8)
+
+
+def test_cli_search_one_process_per_shard_under_torchrun(tmp_path):
+    """`morna search` launched as `torch.distributed.run --nproc-per-node 2` on a file set of two shards: every rank loads ITS
+    shard, the ranks answer together (dist.ShardedSearch: RCCL inside the library when every rank has a GPU, gloo through
+    the host when they share one, as here) and rank 0 prints -- the lines the single process prints over the same file
+    set, by member and for a raw-format stream with --exact."""
+    import socket
+    import subprocess
+    import sys
+    from morna_amd import cli
+    from morna_amd.synth import synthetic_intropolis
+    d = synthetic_intropolis(900, J=1200)
+    src = str(tmp_path / "i.tsv.gz")
+    lines = []
+    for j, k in enumerate(d["keys"]):
+        lo, hi = d["row_ptr"][j], d["row_ptr"][j + 1]
+        lines.append("\t".join(k.split(" ") + ["+", "GT", "AG", ",".join(map(str, d["samples"][lo:hi])),
+                                               ",".join(map(str, d["cov"][lo:hi]))]) + "\n")
+    _write_gz(src, lines)
+    base = str(tmp_path / "two")
+    assert cli.main(["index", "--intropolis", src, "-x", base, "--features", "96", "--n-trees", "5", "-t", "40", "--shards", "2"]) == 0
+    sample = int(d["samples"][d["row_ptr"][7] + 3])
+    q = []
+    for j, k in enumerate(d["keys"]):
+        lo, hi = d["row_ptr"][j], d["row_ptr"][j + 1]
+        hit = np.nonzero(d["samples"][lo:hi] == sample)[0]
+        if len(hit):
+            c, a, b = k.split(" ")
+            q.append("%s\t%s\t%s\t%d\n" % (c, a, b, d["cov"][lo + hit[0]]))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def torchrun(argv, stdin_text=None):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                            "127.0.0.1", "--master-port", str(port), "-m", "morna_amd.cli"] + argv, cwd=root, input=stdin_text,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [ln for ln in r.stdout.splitlines() if ln[:1].isdigit()]
+
+    def single(argv, stdin_text=None):
+        out = io.StringIO()
+        assert cli.main(argv, stdin=io.StringIO(stdin_text or ""), stdout=out) == 0
+        return [ln for ln in out.getvalue().splitlines() if ln[:1].isdigit()]
+
+    by_member = ["search", "-x", base, "-q", str(sample), "-d", "-r", "8", "--search-k", "-1"]
+    assert torchrun(by_member) == single(by_member) and len(single(by_member)) == 8
+    stream = ["search", "-x", base, "-f", "raw", "--exact", "-d", "-r", "8"]
+    assert torchrun(stream, "".join(q)) == single(stream, "".join(q))
