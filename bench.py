@@ -365,7 +365,10 @@ def main():
         n_items, nnz_local, id_offset = prep["n_items"], int(len(prep["ids"])), 0
         bounds = None
     t_stage = time.perf_counter() - t_stage
-    sharded = ShardedSearch(index, rank, world, n_items) if (world > 1 or force_sharded) else None
+    # the exchange inside the library (its own RCCL communicator); should that communicator fail to come up on this node the
+    # ranks agree on torch.distributed's all-gather between the library's two halves instead -- same kernels, same stream
+    sharded = ShardedSearch(index, rank, world, n_items, transport="auto" if args.backend == "nccl" else None) \
+        if (world > 1 or force_sharded) else None
     n_each = None
     if strong:
         # the SAME queries whatever the number of GPUs: Q rows of the whole index; a rank hands over those it owns
@@ -598,8 +601,10 @@ def main():
             "config": {"workload": workload,
                        "samples_total": n_total, "samples_per_gpu": n_items, "features": D, "n_trees": T, "queries": Q, "k": k,
                        "search_k": args.search_k, "nnz_per_gpu": nnz_local, "junction_lines": int(len(prep["idf"])),
-                       "parallelism": "rows sharded over %d GPU(s)%s, RCCL all-gather of per-shard top-k inside the library"
-                                      % (world, " (one data set, global idf and ids)" if strong else " (a data set per GPU)")},
+                       "parallelism": "rows sharded over %d GPU(s)%s, RCCL all-gather of per-shard top-k%s"
+                                      % (world, " (one data set, global idf and ids)" if strong else " (a data set per GPU)",
+                                         "" if sharded is None else " -- transport: %s%s" % (
+                                             sharded.transport, " (%s)" % sharded.transport_note if sharded.transport_note else ""))},
             "index_samples_per_sec": n_total * args.steps / tb,
             "queries_per_sec": Q * args.steps / tq,
             # if the junction lines had to cross PCIe on every step (pageable host buffers, measured once)

@@ -26,27 +26,50 @@ class ShardedSearch(object):
     (CPU tests with a stand-in index; rehearsals of N ranks on fewer GPUs): per-shard answers through the host, gloo
     all-gather, host merge -- the same merges (shards.py), so both paths give one answer."""
 
-    def __init__(self, index, rank, world, n_local, group=None):
+    def __init__(self, index, rank, world, n_local, group=None, transport=None):
+        """transport (backend "nccl" only): "library" (default) -- the communicator inside libmorna_hip; "torch" -- the same
+        kernels with torch.distributed issuing the all-gathers between the library's exported halves of the exchange
+        (morna_*_packed), on the handle's own stream; "auto" -- the library's, or torch's when the library's communicator
+        cannot be made on some rank (the ranks agree).  `self.transport` says which one runs."""
         self.index, self.rank, self.world, self.group = index, rank, world, group
-        self.in_library = dist.get_backend(group) == "nccl" and hasattr(index, "comm_init")
-        self.device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" \
-            else torch.device("cpu")
+        nccl = dist.get_backend(group) == "nccl"
+        self.device = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+        transport = transport or "library"
+        self.in_library = nccl and hasattr(index, "comm_init") and transport in ("library", "auto")
+        self.transport = "gloo-host" if not nccl else "torch"
         if self.in_library:
-            try:                                   # a communicator from an earlier ShardedSearch over this handle
-                have = index.comm_info(offsets=False)[:2]
-            except RuntimeError:
-                have = None
-            if have != (rank, world):
-                if have is not None:
-                    index.comm_destroy()
-                uid = [index.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0, group=group, device=self.device)
-                index.comm_init(uid[0], rank, world)
+            err = None
+            try:
+                try:                               # a communicator from an earlier ShardedSearch over this handle
+                    have = index.comm_info(offsets=False)[:2]
+                except RuntimeError:
+                    have = None
+                if have != (rank, world):
+                    if have is not None:
+                        index.comm_destroy()
+                    uid = [index.comm_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(uid, src=0, group=group, device=self.device)
+                    index.comm_init(uid[0], rank, world)
+            except Exception as e:                 # noqa: BLE001 -- under "auto" the ranks vote below
+                if transport != "auto":
+                    raise
+                err = e
+            if transport == "auto":
+                ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=self.device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+                if int(ok.item()) == 0:
+                    if err is None:
+                        index.comm_destroy()
+                    self.in_library = False
+                    self.transport_note = "library communicator failed on a rank: %s" % (err,)
+        if self.in_library:
+            self.transport = "library"
             self.sizes = np.diff(index.comm_info()[2]).tolist()
         else:
             sizes = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(world)]
             dist.all_gather(sizes, torch.tensor([n_local], dtype=torch.int64, device=self.device), group=group)
             self.sizes = [int(s.item()) for s in sizes]
+        self.transport_note = getattr(self, "transport_note", None)
         if self.sizes[rank] != n_local:
             raise ValueError("shard %d holds %d items, the caller says %d" % (rank, self.sizes[rank], n_local))
         self.offsets = np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int64)
@@ -89,12 +112,58 @@ class ShardedSearch(object):
             raise ValueError("n_each must list every rank's query count, this rank's being len(items)")
         return list(n_each)
 
+    # ---- transport "torch": the library's halves of the exchange with torch.distributed's all-gather between them, all
+    # of it enqueued on the handle's own stream (torch.cuda.ExternalStream): no host wait before the merged result
+    def _torch_device_path(self):
+        return (self.transport == "torch" and hasattr(self.index, "get_nns_by_vector_packed")
+                and self.n_total < 2 ** 31 and self.world <= 64)
+
+    def _lib_stream(self):
+        if getattr(self, "_ext_stream", None) is None:
+            self._ext_stream = torch.cuda.ExternalStream(self.index.stream_ptr(), device=self.device)
+        return self._ext_stream
+
+    def _torch_search(self, q_ptr, nq, k, search_k, keep=None):
+        with torch.cuda.stream(self._lib_stream()):
+            packed = torch.empty((nq, 2 * k), dtype=torch.int32, device=self.device)
+            self.index.get_nns_by_vector_packed(q_ptr, nq, k, search_k, int(self.offsets[self.rank]), packed.data_ptr())
+            gathered = torch.empty((self.world, nq, 2 * k), dtype=torch.int32, device=self.device)
+            dist.all_gather_into_tensor(gathered, packed, group=self.group)
+            ids, d, cnt = self.index.merge_topk_packed(gathered.data_ptr(), self.world, nq, k, k)   # waits for the stream
+        del keep
+        return ids.astype(np.int64), d, cnt
+
+    def _torch_exact(self, k, nq, **query):
+        msg = self.index.exact_packed_bytes(nq, k)
+        with torch.cuda.stream(self._lib_stream()):
+            mine = torch.empty(msg, dtype=torch.uint8, device=self.device)
+            self.index.exact_search_packed(mine.data_ptr(), k, int(self.offsets[self.rank]), **query)
+            gathered = torch.empty((self.world, msg), dtype=torch.uint8, device=self.device)
+            dist.all_gather_into_tensor(gathered, mine, group=self.group)
+            ids, d, cnt = self.index.merge_exact_packed(gathered.data_ptr(), self.world, nq, k, k)
+        return ids.astype(np.int64), d, cnt
+
+    def _torch_gather_rows(self, items, n_each):
+        """every rank's query rows, HBM -> xGMI -> HBM: a device tensor [sum n_each, f] (on the handle's stream)"""
+        n_max, f = max(n_each), self.index.f
+        with torch.cuda.stream(self._lib_stream()):
+            mine = torch.zeros((n_max, f), dtype=torch.float32, device=self.device)
+            if len(items):
+                self.index.get_item_vectors_dev(items, mine.data_ptr())
+            allq = torch.empty((self.world, n_max, f), dtype=torch.float32, device=self.device)
+            dist.all_gather_into_tensor(allq, mine, group=self.group)
+            Q = torch.cat([allq[g, :n_each[g]] for g in range(self.world)], dim=0).contiguous()
+        return Q, (mine, allq)
+
     def get_nns_by_vector(self, Q, k, search_k=-1):
         """Q: [nq, f] fp32, identical on every rank.  Returns merged global ids,
         distances and counts on every rank."""
         if self.in_library:
             ids, d, cnt = self.index.get_nns_by_vector_sharded(Q, k, search_k)
             return ids.astype(np.int64), d, cnt
+        if self._torch_device_path() and k <= 255:
+            Q = np.ascontiguousarray(Q, dtype=np.float32)
+            return self._torch_search(Q.ctypes.data, Q.shape[0], k, search_k)
         ids, d, cnt = self.index.get_nns_by_vector_batch(Q, k, search_k)
         return self._gather_merge(ids, d, k)
 
@@ -105,6 +174,9 @@ class ShardedSearch(object):
         if self.in_library:
             ids, d, cnt = self.index.exact_search_sharded(Q, k)
             return ids.astype(np.int64), d, cnt
+        if self._torch_device_path():
+            Q = np.ascontiguousarray(Q, dtype=np.float64)
+            return self._torch_exact(k, Q.shape[0], Q=Q)
         return self._exact_merge(*self.index.exact_search_batch(Q, k), k=k)
 
     def _exact_merge(self, ids, d, cnt, k):
@@ -134,6 +206,9 @@ class ShardedSearch(object):
         if self.in_library:
             ids, d, cnt = self.index.get_nns_by_item_sharded(items, k, search_k, n_each=n_each)
             return ids.astype(np.int64), d, cnt
+        if self._torch_device_path() and k <= 255:
+            Q, keep = self._torch_gather_rows(items, n_each)
+            return self._torch_search(Q.data_ptr(), Q.shape[0], k, search_k, keep=(Q, keep))
         return self.get_nns_by_vector(self._gather_rows(items, n_each), k, search_k)
 
     def exact_search_by_local_items(self, items, k, n_each=None):
@@ -143,4 +218,9 @@ class ShardedSearch(object):
         if self.in_library:
             ids, d, cnt = self.index.exact_search_by_item_sharded(items, k, n_each)
             return ids.astype(np.int64), d, cnt
+        if self._torch_device_path():
+            Q, keep = self._torch_gather_rows(items, n_each)
+            out = self._torch_exact(k, Q.shape[0], q_dev=(Q.data_ptr(), Q.shape[0]))
+            del keep
+            return out
         return self.exact_search(self._gather_rows(items, n_each).astype(np.float64), k)

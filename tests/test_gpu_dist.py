@@ -293,3 +293,47 @@ def test_exact_packed_exchange_equals_host_merge():
     sel = [j for j, i in enumerate(items[3:]) if bounds[2] <= i < bounds[3]]
     assert m4.cpu().numpy()[:len(own) * k * 4].view(np.int32).reshape(len(own), k).tolist() == (ref_ids[sel] + bounds[2]).tolist()
     del m3
+
+
+def test_torch_transport_one_rank_rccl_equals_the_library_transport():
+    """dist.ShardedSearch on a 1-rank RCCL process group, both device transports: the communicator inside the library
+    (morna_*_sharded) and torch.distributed's all_gather_into_tensor between the library's exported halves
+    (morna_get_nns_by_vector_packed / morna_merge_topk_packed, morna_exact_search_packed / morna_merge_exact_packed,
+    morna_get_item_vectors_dev) on the handle's stream -- the fallback bench.py's "auto" agrees on when the library's
+    communicator cannot be made.  Same answers as the plain entry points, approximate and exact, by vector and by item."""
+    import torch
+    import torch.distributed as dist
+    from morna_amd.annoy import AnnoyIndex
+    from morna_amd.dist import ShardedSearch
+    X = _rows()
+    a = AnnoyIndex(F)
+    a.add_items(X)
+    a.build(T)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.default_rng(5)
+        items = rng.choice(len(X), 90, replace=False).astype(np.int32)
+        Q = np.ascontiguousarray(X[items] + 0.01 * rng.standard_normal((90, F)).astype(np.float32))
+        want_v = a.get_nns_by_vector_batch(Q, K, -1)
+        want_i = a.get_nns_by_item_batch(items, K, 60)
+        want_e = a.exact_search_batch(Q.astype(np.float64), K)
+        want_ei = a.exact_search_by_item_batch(items, K)
+        for transport in ("torch", "library", "auto"):
+            ss = ShardedSearch(a, 0, 1, len(X), transport=transport)
+            assert ss.transport == ("torch" if transport == "torch" else "library") and ss.offsets.tolist() == [0, len(X)]
+            for got, want in ((ss.get_nns_by_vector(Q, K, -1), want_v),
+                              (ss.get_nns_by_local_items(items, K, 60, n_each=[len(items)]), want_i),
+                              (ss.exact_search(Q.astype(np.float64), K), want_e),
+                              (ss.exact_search_by_local_items(items, K, n_each=[len(items)]), want_ei)):
+                assert got[0].tolist() == want[0].astype(np.int64).tolist(), transport
+                assert np.asarray(got[1]).tobytes() == want[1].tobytes() and got[2].tolist() == want[2].tolist(), transport
+            ss.close()
+    finally:
+        dist.destroy_process_group()
