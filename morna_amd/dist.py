@@ -47,8 +47,15 @@ class ShardedSearch(object):
                 if have != (rank, world):
                     if have is not None:
                         index.comm_destroy()
-                    uid = [index.comm_unique_id() if rank == 0 else None]
+                    uid = [None]
+                    if rank == 0:
+                        try:
+                            uid = [index.comm_unique_id()]
+                        except Exception as e:     # noqa: BLE001 -- rank 0 still takes part in the broadcast below
+                            err = e
                     dist.broadcast_object_list(uid, src=0, group=group, device=self.device)
+                    if uid[0] is None:
+                        raise err or RuntimeError("rank 0 could not make a communicator id")
                     index.comm_init(uid[0], rank, world)
             except Exception as e:                 # noqa: BLE001 -- under "auto" the ranks vote below
                 if transport != "auto":
